@@ -1,0 +1,209 @@
+/*
+ * rslam.h -- C ABI of the MI355X-native 1-point-RANSAC EKF update hot path.
+ *
+ * Drop-in boundary for plumewind/ransac_slam.  The reference exposes no plugin
+ * or FFI interface for this path: it is reached by five direct C++ member
+ * calls from System::TrackRunning (src/System.cpp:117,120,123,126,129) that
+ * communicate only through ExtendKF's public members
+ * (include/ransac_slam/ExtendKF.h:154-169).  The entry points below are what a
+ * ~40-line adapter replacing the bodies of those five calls binds to (see
+ * INTEGRATION.md).  All matrices are FP64, column-major (Eigen default).
+ *
+ * Conventions
+ *   - every function returns RSLAM_OK (0) or a negative RSLAM_ERR_* code and
+ *     never aborts the host process (the reference exit()s / Eigen-asserts);
+ *   - pointers are borrowed for the duration of the call, caller keeps
+ *     ownership; "host" / "device" says where the memory must live;
+ *   - a context is not thread-safe; different contexts are independent;
+ *   - there is NO CPU fallback: rslam_create fails with RSLAM_ERR_NO_DEVICE
+ *     when no HIP device is usable.
+ */
+#ifndef RSLAM_H
+#define RSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSLAM_OK                  0
+#define RSLAM_ERR_ARG            -1  /* null pointer / size out of range              */
+#define RSLAM_ERR_NO_DEVICE      -2  /* no usable HIP device (no CPU fallback exists)  */
+#define RSLAM_ERR_HIP            -3  /* a HIP runtime call failed                      */
+#define RSLAM_ERR_STATE          -4  /* call order violated (e.g. update before predict) */
+#define RSLAM_ERR_REF_ASSERT     -5  /* input on which the reference hits an Eigen assert
+                                        (compat mode, Tracking.cpp:498, m_euc != m_id)  */
+#define RSLAM_ERR_NOT_SPD        -6  /* innovation covariance not positive definite    */
+#define RSLAM_ERR_IC_NOT_VISIBLE -7  /* ic[i] set for a feature predicted not visible  */
+
+#define RSLAM_FEAT_INVERSE_DEPTH 0   /* "inversedepth": 6 state entries (ExtendKF.cpp:71) */
+#define RSLAM_FEAT_CARTESIAN     1   /* "cartesian":    3 state entries (ExtendKF.cpp:80) */
+
+/* CamParam, include/ransac_slam/System.h:69-82, filled at src/System.cpp:34-58.
+ * f is the reference's cam.f (= YAML Camera.fps, focal length in the unit of dx). */
+typedef struct rslam_camera {
+    double k1, k2;      /* radial distortion                       */
+    double Cx, Cy;      /* principal point, pixels                 */
+    double f;           /* focal length                            */
+    double dx, dy;      /* pixel pitch                             */
+    int32_t nRows, nCols;
+} rslam_camera;
+
+typedef struct rslam_config {
+    rslam_camera cam;
+    double  sigma_z;     /* RANSAC pixel threshold = std_z, Tracking.cpp:356            */
+    double  p_success;   /* 0.99, Tracking.cpp:354                                      */
+    int32_t n_hyp_init;  /* 1000, Tracking.cpp:357                                      */
+    double  chi2_gate;   /* 5.9915, Tracking.cpp:576                                    */
+    int32_t compat;      /* 1 = reproduce reference quirks Q1 (Tracking.cpp:448),
+                            Q2 (:498), Q6 (ExtendKF.cpp:627), Q7 (Tracking.cpp:589);
+                            0 = corrected arithmetic                                    */
+    int32_t adaptive;    /* 1 = replay the adaptive termination of Tracking.cpp:531-537;
+                            0 = evaluate exactly n_draws hypotheses (benchmark)         */
+    int32_t dedup;       /* 1 = score each distinct hypothesised feature once and map
+                            supports back (identical results, <= m hypotheses scored)   */
+    int32_t reserved;
+} rslam_config;
+
+/* State-vector layout: x = [r(3) q(4) v(3) w(3) | feature 0 | feature 1 | ...]
+ * (ExtendKF.cpp:59-61,69-88).  offset[i] is the state index of feature i. */
+typedef struct rslam_layout {
+    int32_t n;               /* state dimension = 13 + 6*#id + 3*#cartesian */
+    int32_t L;               /* number of features                          */
+    const uint8_t* type;     /* L entries, RSLAM_FEAT_*                     */
+    const int32_t* offset;   /* L entries                                   */
+} rslam_layout;
+
+/* per-stage device times of the last frame, microseconds (hipEvent) */
+typedef struct rslam_stage_times {
+    double predict_us;     /* K1  h, Jacobians, S_i                         */
+    double pht_us;         /* K2  P*H^T for matched features                */
+    double score_us;       /* K3+K4 hypothesis scoring                      */
+    double select_us;      /* K5  consensus replay                          */
+    double update_li_us;   /* K6-K11 low-innovation update (all kernels)    */
+    double rescue_us;      /* K12 rescue gate                               */
+    double update_hi_us;   /* high-innovation update                        */
+    double rank_update_us; /* K10 alone (covariance rank-r update, LI pass) */
+    double factor_us;      /* K8 alone (blocked Cholesky + solves, LI pass) */
+    double total_us;
+} rslam_stage_times;
+
+typedef struct rslam_ctx rslam_ctx;
+
+int rslam_create (const rslam_config* cfg, int device, rslam_ctx** out);
+int rslam_destroy(rslam_ctx* ctx);
+const char* rslam_error_string(int code);
+const char* rslam_version(void);
+
+/* ------------------------------------------------------------------ *
+ *  Drop-in (host-pointer) API.  P round-trips over PCIe.             *
+ * ------------------------------------------------------------------ */
+
+/* Segment 1: replaces Tracking::search_IC_matches lines 35-44
+ * (predict_camera_measurements, calculate_derivatives, S_i = H_i P H_i^T + R_i).
+ * x_pred = x_k_km1 (n), P_pred = p_k_km1 (n*n, ld = n), both host.
+ * Outputs (host): h (L*2, row i = feature i), visible (L), S (L*4, 2x2 col-major).
+ * For features that are not visible h and S entries are left untouched. */
+int rslam_predict(rslam_ctx* ctx, const rslam_layout* layout,
+                  const double* x_pred, const double* P_pred,
+                  double* h, uint8_t* visible, double* S);
+
+/* Segment 2: replaces System.cpp:120-129 (ransac_hypotheses,
+ * ekf_update_li_inliers, rescue_hi_inliers, ekf_update_hi_inliers).
+ * z (L*2) measured pixel of feature i (read only where ic[i]); ic (L) =
+ * individually_compatible; draws[n_draws] in [0,1) replace the reference's
+ * rand() stream (ExtendKF.cpp:230, one draw per hypothesis, Tracking.cpp:412).
+ * Outputs (host): x_new = x_k_k (n); P_new = p_k_k (n*n) or NULL to keep it
+ * device-resident (rslam_fetch_cov); li/hi (L) inlier flags; scalars. */
+int rslam_ransac_update(rslam_ctx* ctx, const double* z, const uint8_t* ic,
+                        const double* draws, int32_t n_draws,
+                        double* x_new, double* P_new,
+                        uint8_t* li, uint8_t* hi,
+                        int32_t* best_hyp, int32_t* best_support,
+                        int32_t* hyps_evaluated);
+
+int rslam_fetch_cov  (rslam_ctx* ctx, double* P /* host, n*n */);
+int rslam_fetch_state(rslam_ctx* ctx, double* x /* host, n   */);
+int rslam_timings    (rslam_ctx* ctx, rslam_stage_times* out);
+
+/* ------------------------------------------------------------------ *
+ *  Resident API: inputs are loaded once, every step runs from HBM,   *
+ *  nothing synchronises with the host until rslam_sync.  Used by the *
+ *  benchmark and by the multi-GPU hypothesis sharding (one process   *
+ *  per GPU; the exchange of supports happens between step_score and  *
+ *  step_update on the caller's side, e.g. an RCCL all-gather).       *
+ * ------------------------------------------------------------------ */
+
+/* hipStream_t to enqueue on (NULL = the context's own stream). */
+int rslam_set_stream(rslam_ctx* ctx, void* hip_stream);
+
+/* Upload one frame's inputs (host pointers) into context-owned HBM buffers. */
+int rslam_load_frame(rslam_ctx* ctx, const rslam_layout* layout,
+                     const double* x_pred, const double* P_pred,
+                     const double* z, const uint8_t* ic,
+                     const double* draws, int32_t n_draws);
+
+/* Segment 1 on the resident frame. */
+int rslam_step_predict(rslam_ctx* ctx);
+
+/* K2-K4 for hypotheses [hyp_begin, hyp_end) of the draw list: writes
+ * d_supports[hyp_begin..hyp_end) (DEVICE pointer, int32, n_draws entries). */
+int rslam_step_score(rslam_ctx* ctx, int32_t hyp_begin, int32_t hyp_end,
+                     int32_t* d_supports);
+
+/* K5-K12 + both updates, from the complete support list (DEVICE pointer). */
+int rslam_step_update(rslam_ctx* ctx, const int32_t* d_supports);
+
+/* Whole frame = step_predict + step_score(0, n_draws) + step_update with a
+ * context-owned support buffer; replayed from a hipGraph when use_graph != 0. */
+int rslam_step_frame(rslam_ctx* ctx, int32_t use_graph);
+
+/* Block until the stream is idle; returns the device-side status of the
+ * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...). */
+int rslam_sync(rslam_ctx* ctx);
+
+/* Results of the last frame (host pointers; any may be NULL). Synchronises. */
+int rslam_fetch_prediction(rslam_ctx* ctx, double* h, uint8_t* visible, double* S);
+int rslam_fetch_results(rslam_ctx* ctx, double* x_new, uint8_t* li, uint8_t* hi,
+                        int32_t* best_hyp, int32_t* best_support,
+                        int32_t* hyps_evaluated, int32_t* n_li, int32_t* n_hi);
+/* Per-hypothesis supports and 64-bit inlier masks of the last scored slice
+ * (host pointers; masks: n_draws * ceil(m/64) words, bit j = j-th matched
+ * feature in feature order). */
+int rslam_fetch_supports(rslam_ctx* ctx, int32_t* supports, uint64_t* masks,
+                         int32_t* n_mask_words);
+
+/* ------------------------------------------------------------------ *
+ *  Kernel-level entry points (device pointers) used by the roofline  *
+ *  measurements and kernel parity tests.                             *
+ * ------------------------------------------------------------------ */
+
+/* C(n x n, ldc) = sym(A)(n x n, lda) - Y(n x r, ldy) * Y^T  with
+ * sym(A) = (A + A^T)/2: the covariance rank-r update of ExtendKF.cpp:608-609
+ * in its factored form (K S K^T = Y Y^T, Y = P H^T L^-T).  n, r arbitrary;
+ * buffers must be padded: lda, ldc, ldy >= round_up(n, 64), Y has
+ * round_up(r, 4) columns, pad entries zero.  FP64 MFMA kernel (K10). */
+int rslam_k_rank_update(rslam_ctx* ctx, int32_t n, int32_t r,
+                        const double* dA, int32_t lda,
+                        const double* dY, int32_t ldy,
+                        double* dC, int32_t ldc);
+
+/* C(m x n) = alpha * A(m x k) * B(n x k)^T + beta * C, dense FP64 MFMA GEMM
+ * (the dense form of P*H^T, Tracking.cpp:42,420-421).  All dimensions must be
+ * padded to multiples of 64 (k: 4) with zero fill. */
+int rslam_k_gemm_nt(rslam_ctx* ctx, int32_t m, int32_t n, int32_t k,
+                    double alpha, const double* dA, int32_t lda,
+                    const double* dB, int32_t ldb,
+                    double beta, double* dC, int32_t ldc);
+
+/* Peak-rate probe: issues back-to-back v_mfma_f64_16x16x4_f64 from every CU
+ * and returns the measured TFLOP/s (prints nothing). */
+int rslam_k_mfma_f64_peak(rslam_ctx* ctx, double* tflops);
+/* Streaming-copy probe: measured HBM GB/s for a bytes-sized device copy. */
+int rslam_k_hbm_copy_peak(rslam_ctx* ctx, int64_t bytes, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSLAM_H */

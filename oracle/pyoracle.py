@@ -1,0 +1,243 @@
+"""ctypes binding of the CPU oracle (oracle/rslam_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(),
+and the cpu_baseline leg of bench.py -- never the product path.
+PARITY UNPINNED (see rslam_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ransac_slam_amd.ctypes_defs import Config, Layout, make_layout
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "librslam_oracle.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (-O2, no FMA contraction, 1 thread)."""
+    src = os.path.join(_HERE, "rslam_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
+                                                   os.path.getmtime(os.path.join(_HERE, "rslam_oracle.h")),
+                                                   os.path.getmtime(os.path.join(_HERE, "..", "include", "rslam.h")))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_structure.argtypes = [C.c_void_p, C.c_int]
+        L.orc_predict.argtypes = [C.c_void_p, C.POINTER(Layout), _dp, _dp, _dp, _u8p, _dp]
+        L.orc_ransac_update.argtypes = [C.c_void_p, _dp, _u8p, _dp, C.c_int32, _dp, _dp, _u8p, _u8p,
+                                        _i32p, _i32p, _i32p]
+        L.orc_ransac_only.argtypes = [C.c_void_p, _dp, _u8p, _dp, C.c_int32, C.c_int32, _u8p,
+                                      _i32p, _i32p, _i32p]
+        L.orc_get_supports.argtypes = [C.c_void_p, _i32p, _i32p, _u64p, _i32p]
+        L.orc_get_margins.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_get_H.argtypes = [C.c_void_p, _dp]
+        L.orc_get_li_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_q2r.argtypes = [_dp, _dp]
+        L.orc_hu.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_distort_fm.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_undistort_fm.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_jacob_undistor_fm.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_dRq_times_a_by_dq.argtypes = [_dp, _dp, _dp]
+        L.orc_hi_cartesian.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_adaptive_n_hyp.argtypes = [C.c_double, C.c_int, C.c_int]
+        L.orc_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_inverse_lu.argtypes = [C.c_int, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _p(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(f"oracle returned {code}")
+        self.code = code
+
+
+class Oracle:
+    """Frame-level wrapper with the same two segments as the C ABI."""
+
+    def __init__(self, cfg: Config, structure=0):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = lib().orc_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            raise OracleError(rc)
+        lib().orc_set_structure(self._h, structure)
+        self.n = self.L = 0
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def predict(self, types, x_pred, P_pred):
+        lay, keep = make_layout(types)
+        self._keep = keep
+        self.n, self.L = lay.n, lay.L
+        x = np.ascontiguousarray(x_pred, dtype=np.float64)
+        P = np.asfortranarray(P_pred, dtype=np.float64)
+        assert x.shape == (self.n,) and P.shape == (self.n, self.n)
+        h = np.full((self.L, 2), np.nan)
+        vis = np.zeros(self.L, np.uint8)
+        S = np.full((self.L, 4), np.nan)
+        rc = lib().orc_predict(self._h, C.byref(lay), _p(x), _p(P), _p(h), _p(vis, _u8p), _p(S))
+        if rc:
+            raise OracleError(rc)
+        return h, vis, S
+
+    def ransac_update(self, z, ic, draws):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        ic = np.ascontiguousarray(ic, dtype=np.uint8)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        x_new = np.zeros(self.n)
+        P_new = np.zeros((self.n, self.n), order="F")
+        li = np.zeros(self.L, np.uint8)
+        hi = np.zeros(self.L, np.uint8)
+        bh, bs, he = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = lib().orc_ransac_update(self._h, _p(z), _p(ic, _u8p), _p(draws), len(draws), _p(x_new), _p(P_new),
+                                     _p(li, _u8p), _p(hi, _u8p), C.byref(bh), C.byref(bs), C.byref(he))
+        if rc:
+            raise OracleError(rc)
+        return dict(x_new=x_new, P_new=P_new, li=li, hi=hi, best_hyp=bh.value, best_support=bs.value,
+                    hyps_evaluated=he.value)
+
+    def ransac_only(self, z, ic, draws, max_iters=0):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        ic = np.ascontiguousarray(ic, dtype=np.uint8)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        li = np.zeros(self.L, np.uint8)
+        bh, bs, he = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = lib().orc_ransac_only(self._h, _p(z), _p(ic, _u8p), _p(draws), len(draws), max_iters,
+                                   _p(li, _u8p), C.byref(bh), C.byref(bs), C.byref(he))
+        if rc:
+            raise OracleError(rc)
+        return dict(li=li, best_hyp=bh.value, best_support=bs.value, hyps_evaluated=he.value)
+
+    def supports(self):
+        words = C.c_int32()
+        n_eval = lib().orc_get_supports(self._h, None, None, None, C.byref(words))
+        sup = np.zeros(max(n_eval, 1), np.int32)
+        pos = np.zeros(max(n_eval, 1), np.int32)
+        masks = np.zeros((max(n_eval, 1), max(words.value, 1)), np.uint64)
+        lib().orc_get_supports(self._h, _p(sup, _i32p), _p(pos, _i32p), _p(masks, _u64p), C.byref(words))
+        return sup[:n_eval], pos[:n_eval], masks[:n_eval, :words.value]
+
+    def margins(self):
+        a, b = C.c_double(), C.c_double()
+        lib().orc_get_margins(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def H(self):
+        H = np.zeros((self.L, self.n, 2))   # block i is 2 x n col-major == (n,2) C-order transposed view
+        rc = lib().orc_get_H(self._h, _p(H))
+        if rc:
+            raise OracleError(rc)
+        return np.transpose(H, (0, 2, 1))   # L x 2 x n
+
+    def li_state(self):
+        x = np.zeros(self.n)
+        P = np.zeros((self.n, self.n), order="F")
+        lib().orc_get_li_state(self._h, _p(x), _p(P))
+        return x, P
+
+
+# ---- unit functions -------------------------------------------------------
+def q2r(q):
+    q = np.ascontiguousarray(q, np.float64)
+    R = np.zeros((3, 3), order="F")
+    lib().orc_q2r(_p(q), _p(R))
+    return R
+
+
+def _cam_call(fn, cam, vin, nout):
+    vin = np.ascontiguousarray(vin, np.float64)
+    out = np.zeros(nout)
+    fn(C.byref(cam), _p(vin), _p(out))
+    return out
+
+
+def hu(cam, y):
+    return _cam_call(lib().orc_hu, cam, y, 2)
+
+
+def distort_fm(cam, uv):
+    return _cam_call(lib().orc_distort_fm, cam, uv, 2)
+
+
+def undistort_fm(cam, uvd):
+    return _cam_call(lib().orc_undistort_fm, cam, uvd, 2)
+
+
+def jacob_undistor_fm(cam, uvd):
+    return _cam_call(lib().orc_jacob_undistor_fm, cam, uvd, 4).reshape(2, 2, order="F")
+
+
+def dRq_times_a_by_dq(q, a):
+    q = np.ascontiguousarray(q, np.float64)
+    a = np.ascontiguousarray(a, np.float64)
+    out = np.zeros((3, 4), order="F")
+    lib().orc_dRq_times_a_by_dq(_p(q), _p(a), _p(out))
+    return out
+
+
+def hi_cartesian(cam, hrl):
+    hrl = np.ascontiguousarray(hrl, np.float64)
+    uv = np.zeros(2)
+    vis = lib().orc_hi_cartesian(C.byref(cam), _p(hrl), _p(uv))
+    return bool(vis), uv
+
+
+def adaptive_n_hyp(p, support, num_ic):
+    return lib().orc_adaptive_n_hyp(p, support, num_ic)
+
+
+def update(compat, x, P, H, z, h):
+    n, r = len(x), len(z)
+    x = np.ascontiguousarray(x, np.float64)
+    P = np.asfortranarray(P, np.float64)
+    H = np.asfortranarray(np.reshape(H, (r, n)), np.float64)
+    z = np.ascontiguousarray(z, np.float64)
+    h = np.ascontiguousarray(h, np.float64)
+    xo = np.zeros(n)
+    Po = np.zeros((n, n), order="F")
+    rc = lib().orc_update(compat, n, r, _p(x), _p(P), _p(H), _p(z), _p(h), _p(xo), _p(Po))
+    if rc:
+        raise OracleError(rc)
+    return xo, Po
+
+
+def inverse_lu(A):
+    A = np.asfortranarray(A, np.float64)
+    n = A.shape[0]
+    out = np.zeros((n, n), order="F")
+    lib().orc_inverse_lu(n, _p(A), _p(out))
+    return out

@@ -1,0 +1,164 @@
+"""Synthetic EKF-SLAM frames for the 1-point-RANSAC update benchmark and tests.
+
+No dataset can be fetched here and BASELINE config 0 (the PGM sequence) cannot
+run, so frames are generated: a camera near the origin, L inverse-depth (or a mix
+with Cartesian) landmarks seen in the 320x240 image of
+examples/Monocular/initialize_param.yaml, a dense SPD prior covariance whose
+dominant uncertainty is the camera pose (as in a converged EKF-SLAM map), and
+measurements z = h(x_true) + noise with a fraction of gross outliers.
+
+The camera functions below restate ExtendKF.cpp:91-102 (q2r), :153-174 (hu),
+:175-204 (distort_fm), :266-285 (undistort_fm) in numpy; they are generator
+utilities, independent of both the HIP path and the C oracle.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .ctypes_defs import FEAT_CARTESIAN, FEAT_INVERSE_DEPTH, default_camera
+
+SEED_BASE = 0x5EED0000
+
+# BASELINE.json configs (index = config id): (L, H)
+CONFIGS = {
+    1: dict(name="C2: 100 landmarks x 200 hypotheses", L=100, H=200),
+    2: dict(name="C3: 300 landmarks x 1000 hypotheses", L=300, H=1000),
+    3: dict(name="C4: 300 landmarks x 4000 hypotheses (sharded)", L=300, H=4000),
+    4: dict(name="C5: 1000 landmarks, r forced large", L=1000, H=1000),
+}
+
+
+def q2r(q):
+    r, x, y, z = q
+    return np.array([
+        [r*r + x*x - y*y - z*z, 2*(x*y - r*z),         2*(z*x + r*y)],
+        [2*(x*y + r*z),         r*r - x*x + y*y - z*z, 2*(y*z - r*x)],
+        [2*(z*x - r*y),         2*(y*z + r*x),         r*r - x*x - y*y + z*z]])
+
+
+def undistort(cam, uvd):
+    xd = (uvd[..., 0] - cam.Cx) * cam.dx
+    yd = (uvd[..., 1] - cam.Cy) * cam.dy
+    rd2 = xd * xd + yd * yd
+    D = 1 + cam.k1 * rd2 + cam.k2 * rd2 * rd2
+    return np.stack([xd * D / cam.dx + cam.Cx, yd * D / cam.dy + cam.Cy], axis=-1)
+
+
+def distort(cam, uv):
+    xu = (uv[..., 0] - cam.Cx) * cam.dx
+    yu = (uv[..., 1] - cam.Cy) * cam.dy
+    ru = np.sqrt(xu * xu + yu * yu)
+    rd = ru / (1 + cam.k1 * ru**2 + cam.k2 * ru**4)
+    for _ in range(10):
+        f = rd + cam.k1 * rd**3 + cam.k2 * rd**5 - ru
+        fp = 1 + 3 * cam.k1 * rd**2 + 5 * cam.k2 * rd**4
+        rd = rd - f / fp
+    D = 1 + cam.k1 * rd**2 + cam.k2 * rd**4
+    return np.stack([xu / D / cam.dx + cam.Cx, yu / D / cam.dy + cam.Cy], axis=-1)
+
+
+def project(cam, x, types, offsets):
+    """h_i(x) for every feature (no visibility gate), L x 2."""
+    t = x[0:3]
+    R = q2r(x[3:7])
+    out = np.zeros((len(types), 2))
+    for i, (ty, o) in enumerate(zip(types, offsets)):
+        if ty == FEAT_INVERSE_DEPTH:
+            y = x[o:o + 6]
+            m = np.array([np.cos(y[4]) * np.sin(y[3]), -np.sin(y[4]), np.cos(y[4]) * np.cos(y[3])])
+            hrl = R.T @ ((y[0:3] - t) * y[5] + m)
+        else:
+            hrl = np.linalg.solve(R, x[o:o + 3] - t)
+        uv = np.array([cam.Cx + (hrl[0] / hrl[2]) * cam.f / cam.dx,
+                       cam.Cy + (hrl[1] / hrl[2]) * cam.f / cam.dy])
+        out[i] = distort(cam, uv)
+    return out
+
+
+@dataclass
+class Frame:
+    types: np.ndarray      # uint8 L
+    offsets: np.ndarray    # int32 L
+    n: int
+    x_pred: np.ndarray     # n
+    P_pred: np.ndarray     # n x n, Fortran order (column-major)
+    z: np.ndarray          # L x 2 (row i = feature i)
+    ic: np.ndarray         # uint8 L
+    draws: np.ndarray      # H
+    x_true: np.ndarray
+    outlier: np.ndarray    # bool L (ground truth)
+
+    @property
+    def L(self):
+        return len(self.types)
+
+
+def make_frame(L=16, H=32, seed=0, frac_cartesian=0.0, frac_outlier=0.2, frac_ic=1.0,
+               meas_sigma=0.5, cam=None, pose_sigma_scale=1.0) -> Frame:
+    """One synthetic frame.  Deterministic in (arguments, numpy version)."""
+    cam = cam or default_camera()
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + seed))
+    types = np.where(rng.random(L) < frac_cartesian, FEAT_CARTESIAN, FEAT_INVERSE_DEPTH).astype(np.uint8)
+    widths = np.where(types == FEAT_INVERSE_DEPTH, 6, 3)
+    offsets = (13 + np.concatenate([[0], np.cumsum(widths)[:-1]])).astype(np.int32)
+    n = int(13 + widths.sum())
+
+    x = np.zeros(n)
+    x[0:3] = rng.normal(0, 0.01, 3)
+    q = np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.01, 4)
+    x[3:7] = q / np.linalg.norm(q)
+    x[7:13] = rng.normal(0, 0.01, 6)
+    Rwc = q2r(x[3:7])
+
+    # landmarks: pixel uniform in the image interior, depth uniform in [1, 10] m
+    pix = np.stack([rng.uniform(31, 289, L), rng.uniform(31, 209, L)], axis=-1)
+    und = undistort(cam, pix)
+    depth = rng.uniform(1.0, 10.0, L)
+    diagD = np.zeros(n)
+    diagD[0:3] = (0.01 * pose_sigma_scale) ** 2        # camera position, 1 cm
+    diagD[3:7] = (0.004 * pose_sigma_scale) ** 2       # quaternion, ~0.5 deg
+    diagD[7:13] = 6.25e-4
+    for i in range(L):
+        # ray in the camera frame through the undistorted pixel, then to the world
+        ray_c = np.array([(und[i, 0] - cam.Cx) * cam.dx / cam.f, (und[i, 1] - cam.Cy) * cam.dy / cam.f, 1.0])
+        o = offsets[i]
+        if types[i] == FEAT_INVERSE_DEPTH:
+            anchor = rng.normal(0, 0.05, 3)
+            # point = cam + depth*ray (in the world); direction from the anchor
+            pw = x[0:3] + Rwc @ (ray_c * depth[i])
+            d = pw - anchor
+            dist = np.linalg.norm(d)
+            m = d / dist
+            theta = np.arctan2(m[0], m[2])
+            phi = np.arctan2(-m[1], np.hypot(m[0], m[2]))
+            x[o:o + 6] = [*anchor, theta, phi, 1.0 / dist]
+            diagD[o:o + 3] = 1e-6
+            diagD[o + 3:o + 5] = 1e-7
+            diagD[o + 5] = (0.02 / dist) ** 2
+        else:
+            x[o:o + 3] = x[0:3] + Rwc @ (ray_c * depth[i])
+            diagD[o:o + 3] = 1e-6 * depth[i] ** 2
+
+    # dense low-rank coupling (map <-> camera correlations of a converged filter)
+    U = rng.normal(0, 1.0, (n, 13)) * 3e-4
+    U[0:13, :] *= 3.0
+    P = (U @ U.T)
+    P[np.diag_indices(n)] += diagD
+    P = np.asfortranarray(0.5 * (P + P.T))
+
+    # truth ~ N(x, P) sampled through the factors
+    x_true = x + np.sqrt(diagD) * rng.normal(0, 1, n) + U @ rng.normal(0, 1, 13)
+    h_true = project(cam, x_true, types, offsets)
+    outlier = rng.random(L) < frac_outlier
+    z = h_true + rng.normal(0, meas_sigma, (L, 2))
+    z[outlier] += rng.uniform(-10, 10, (int(outlier.sum()), 2))
+    ic = (rng.random(L) < frac_ic).astype(np.uint8)
+    draws = rng.random(H)
+    return Frame(types=types, offsets=offsets, n=n, x_pred=x, P_pred=P, z=np.ascontiguousarray(z),
+                 ic=ic, draws=draws, x_true=x_true, outlier=outlier)
+
+
+def make_config_frame(config_id: int) -> Frame:
+    """The frames of BASELINE.json configs 1..4 (all inverse-depth landmarks)."""
+    c = CONFIGS[config_id]
+    return make_frame(L=c["L"], H=c["H"], seed=config_id)
