@@ -125,6 +125,8 @@ int rslam_ransac_update(rslam_ctx* ctx, const double* z, const uint8_t* ic,
 
 int rslam_fetch_cov  (rslam_ctx* ctx, double* P /* host, n*n */);
 int rslam_fetch_state(rslam_ctx* ctx, double* x /* host, n   */);
+/* Per-stage hipEvent timing of eager (non-graph) frames: off by default. */
+int rslam_enable_timing(rslam_ctx* ctx, int on);
 int rslam_timings    (rslam_ctx* ctx, rslam_stage_times* out);
 
 /* ------------------------------------------------------------------ *
@@ -183,7 +185,7 @@ int rslam_fetch_supports(rslam_ctx* ctx, int32_t* supports, uint64_t* masks,
  * sym(A) = (A + A^T)/2: the covariance rank-r update of ExtendKF.cpp:608-609
  * in its factored form (K S K^T = Y Y^T, Y = P H^T L^-T).  n, r arbitrary;
  * buffers must be padded: lda, ldc, ldy >= round_up(n, 64), Y has
- * round_up(r, 4) columns, pad entries zero.  FP64 MFMA kernel (K10). */
+ * round_up(r, 32) columns, pad entries zero.  FP64 MFMA kernel (K10). */
 int rslam_k_rank_update(rslam_ctx* ctx, int32_t n, int32_t r,
                         const double* dA, int32_t lda,
                         const double* dY, int32_t ldy,
@@ -191,7 +193,7 @@ int rslam_k_rank_update(rslam_ctx* ctx, int32_t n, int32_t r,
 
 /* C(m x n) = alpha * A(m x k) * B(n x k)^T + beta * C, dense FP64 MFMA GEMM
  * (the dense form of P*H^T, Tracking.cpp:42,420-421).  All dimensions must be
- * padded to multiples of 64 (k: 4) with zero fill. */
+ * padded to multiples of 64 (k: 32) with zero fill. */
 int rslam_k_gemm_nt(rslam_ctx* ctx, int32_t m, int32_t n, int32_t k,
                     double alpha, const double* dA, int32_t lda,
                     const double* dB, int32_t ldb,
@@ -200,6 +202,10 @@ int rslam_k_gemm_nt(rslam_ctx* ctx, int32_t m, int32_t n, int32_t k,
 /* Peak-rate probe: issues back-to-back v_mfma_f64_16x16x4_f64 from every CU
  * and returns the measured TFLOP/s (prints nothing). */
 int rslam_k_mfma_f64_peak(rslam_ctx* ctx, double* tflops);
+/* Same probe with waves_per_simd resident waves per SIMD; also reports the
+ * shader cycles one SIMD spends per MFMA and the in-kernel clock (either may be NULL). */
+int rslam_k_mfma_f64_probe(rslam_ctx* ctx, int32_t waves_per_simd, double* tflops,
+                           double* cycles_per_mfma, double* clock_mhz);
 /* Streaming-copy probe: measured HBM GB/s for a bytes-sized device copy. */
 int rslam_k_hbm_copy_peak(rslam_ctx* ctx, int64_t bytes, double* gbps);
 

@@ -1,0 +1,231 @@
+"""ctypes binding of the product library librslam_hip.so (C ABI: include/rslam.h).
+
+Plumbing only: every call goes to the HIP implementation.  There is no CPU
+fallback -- loading fails loudly when the library is missing and
+``RslamHip()`` raises when no HIP device can be opened.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ctypes_defs import Config, Layout, StageTimes, make_layout
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librslam_hip.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+
+# every symbol include/rslam.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "rslam_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]),
+    "rslam_destroy": (C.c_int, [C.c_void_p]),
+    "rslam_error_string": (C.c_char_p, [C.c_int]),
+    "rslam_version": (C.c_char_p, []),
+    "rslam_predict": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp, _dp, _u8p, _dp]),
+    "rslam_ransac_update": (C.c_int, [C.c_void_p, _dp, _u8p, _dp, C.c_int32, _dp, _dp, _u8p, _u8p, _i32p, _i32p, _i32p]),
+    "rslam_fetch_cov": (C.c_int, [C.c_void_p, _dp]),
+    "rslam_fetch_state": (C.c_int, [C.c_void_p, _dp]),
+    "rslam_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rslam_timings": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
+    "rslam_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rslam_load_frame": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp, _dp, _u8p, _dp, C.c_int32]),
+    "rslam_step_predict": (C.c_int, [C.c_void_p]),
+    "rslam_step_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rslam_step_update": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rslam_step_frame": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rslam_sync": (C.c_int, [C.c_void_p]),
+    "rslam_fetch_prediction": (C.c_int, [C.c_void_p, _dp, _u8p, _dp]),
+    "rslam_fetch_results": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, _i32p, _i32p, _i32p, _i32p, _i32p]),
+    "rslam_fetch_supports": (C.c_int, [C.c_void_p, _i32p, _u64p, _i32p]),
+    "rslam_k_rank_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_int32]),
+    "rslam_k_gemm_nt": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32]),
+    "rslam_k_mfma_f64_peak": (C.c_int, [C.c_void_p, _dp]),
+    "rslam_k_mfma_f64_probe": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "rslam_k_hbm_copy_peak": (C.c_int, [C.c_void_p, C.c_int64, _dp]),
+}
+
+
+class RslamError(RuntimeError):
+    def __init__(self, code, where=""):
+        msg = lib().rslam_error_string(code).decode() if _lib is not None else str(code)
+        super().__init__(f"{where}: rslam error {code} ({msg})")
+        self.code = code
+
+
+def lib():
+    """Load librslam_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP extension is mandatory, there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise RslamError(rc, where)
+
+
+class RslamHip:
+    """One context on one GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, cfg: Config, device=0):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _chk(lib().rslam_create(C.byref(cfg), device, C.byref(self._h)), "rslam_create")
+        self.n = self.L = self.H = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rslam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- drop-in API ----------------------------------------------------
+    def predict(self, types, x_pred, P_pred):
+        lay, keep = make_layout(types)
+        self._keep = keep
+        self.n, self.L = lay.n, lay.L
+        x = np.ascontiguousarray(x_pred, dtype=np.float64)
+        P = np.asfortranarray(P_pred, dtype=np.float64)
+        assert x.shape == (self.n,) and P.shape == (self.n, self.n)
+        h = np.full((self.L, 2), np.nan)
+        vis = np.zeros(self.L, np.uint8)
+        S = np.full((self.L, 4), np.nan)
+        _chk(lib().rslam_predict(self._h, C.byref(lay), _p(x), _p(P), _p(h), _p(vis, _u8p), _p(S)), "rslam_predict")
+        return h, vis, S
+
+    def ransac_update(self, z, ic, draws, want_P=True):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        ic = np.ascontiguousarray(ic, dtype=np.uint8)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        self.H = len(draws)
+        x_new = np.zeros(self.n)
+        P_new = np.zeros((self.n, self.n), order="F") if want_P else None
+        li = np.zeros(self.L, np.uint8)
+        hi = np.zeros(self.L, np.uint8)
+        bh, bs, he = C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(lib().rslam_ransac_update(self._h, _p(z), _p(ic, _u8p), _p(draws), len(draws), _p(x_new),
+                                       _p(P_new) if want_P else None, _p(li, _u8p), _p(hi, _u8p),
+                                       C.byref(bh), C.byref(bs), C.byref(he)), "rslam_ransac_update")
+        return dict(x_new=x_new, P_new=P_new, li=li, hi=hi, best_hyp=bh.value, best_support=bs.value,
+                    hyps_evaluated=he.value)
+
+    # ---- resident API ---------------------------------------------------
+    def set_stream(self, stream_handle):
+        _chk(lib().rslam_set_stream(self._h, C.c_void_p(stream_handle)), "rslam_set_stream")
+
+    def load_frame(self, types, x_pred, P_pred, z, ic, draws):
+        lay, keep = make_layout(types)
+        self._keep = keep
+        self.n, self.L, self.H = lay.n, lay.L, len(draws)
+        x = np.ascontiguousarray(x_pred, dtype=np.float64)
+        P = np.asfortranarray(P_pred, dtype=np.float64)
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        ic = np.ascontiguousarray(ic, dtype=np.uint8)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        _chk(lib().rslam_load_frame(self._h, C.byref(lay), _p(x), _p(P), _p(z), _p(ic, _u8p), _p(draws), len(draws)),
+             "rslam_load_frame")
+
+    def step_predict(self):
+        _chk(lib().rslam_step_predict(self._h), "rslam_step_predict")
+
+    def step_score(self, hyp_begin, hyp_end, d_supports_ptr):
+        _chk(lib().rslam_step_score(self._h, hyp_begin, hyp_end, C.c_void_p(d_supports_ptr)), "rslam_step_score")
+
+    def step_update(self, d_supports_ptr):
+        _chk(lib().rslam_step_update(self._h, C.c_void_p(d_supports_ptr)), "rslam_step_update")
+
+    def step_frame(self, use_graph=True):
+        _chk(lib().rslam_step_frame(self._h, 1 if use_graph else 0), "rslam_step_frame")
+
+    def sync(self):
+        _chk(lib().rslam_sync(self._h), "rslam_sync")
+
+    def enable_timing(self, on=True):
+        _chk(lib().rslam_enable_timing(self._h, 1 if on else 0), "rslam_enable_timing")
+
+    def timings(self):
+        t = StageTimes()
+        _chk(lib().rslam_timings(self._h, C.byref(t)), "rslam_timings")
+        return {k: getattr(t, k) for k, _ in StageTimes._fields_}
+
+    def fetch_prediction(self):
+        h = np.zeros((self.L, 2))
+        vis = np.zeros(self.L, np.uint8)
+        S = np.zeros((self.L, 4))
+        _chk(lib().rslam_fetch_prediction(self._h, _p(h), _p(vis, _u8p), _p(S)), "rslam_fetch_prediction")
+        return h, vis, S
+
+    def fetch_results(self, want_P=True):
+        x_new = np.zeros(self.n)
+        li = np.zeros(self.L, np.uint8)
+        hi = np.zeros(self.L, np.uint8)
+        v = [C.c_int32() for _ in range(5)]
+        _chk(lib().rslam_fetch_results(self._h, _p(x_new), _p(li, _u8p), _p(hi, _u8p), *[C.byref(a) for a in v]),
+             "rslam_fetch_results")
+        out = dict(x_new=x_new, li=li, hi=hi, best_hyp=v[0].value, best_support=v[1].value,
+                   hyps_evaluated=v[2].value, n_li=v[3].value, n_hi=v[4].value)
+        if want_P:
+            P = np.zeros((self.n, self.n), order="F")
+            _chk(lib().rslam_fetch_cov(self._h, _p(P)), "rslam_fetch_cov")
+            out["P_new"] = P
+        return out
+
+    def fetch_supports(self):
+        words = C.c_int32()
+        _chk(lib().rslam_fetch_supports(self._h, None, None, C.byref(words)), "rslam_fetch_supports")
+        sup = np.zeros(max(self.H, 1), np.int32)
+        masks = np.zeros((max(self.H, 1), max(words.value, 1)), np.uint64)
+        _chk(lib().rslam_fetch_supports(self._h, _p(sup, _i32p), _p(masks, _u64p), C.byref(words)),
+             "rslam_fetch_supports")
+        return sup[:self.H], masks[:self.H, :words.value]
+
+    # ---- kernel-level entry points (device pointers) ----------------------
+    def k_rank_update(self, n, r, dA, lda, dY, ldy, dC, ldc):
+        _chk(lib().rslam_k_rank_update(self._h, n, r, C.c_void_p(dA), lda, C.c_void_p(dY), ldy, C.c_void_p(dC), ldc),
+             "rslam_k_rank_update")
+
+    def k_gemm_nt(self, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc):
+        _chk(lib().rslam_k_gemm_nt(self._h, m, n, k, alpha, C.c_void_p(dA), lda, C.c_void_p(dB), ldb, beta,
+                                   C.c_void_p(dC), ldc), "rslam_k_gemm_nt")
+
+    def mfma_f64_peak(self):
+        v = C.c_double()
+        _chk(lib().rslam_k_mfma_f64_peak(self._h, C.byref(v)), "rslam_k_mfma_f64_peak")
+        return v.value
+
+    def mfma_f64_probe(self, waves_per_simd=1):
+        t, cy, mhz = C.c_double(), C.c_double(), C.c_double()
+        _chk(lib().rslam_k_mfma_f64_probe(self._h, waves_per_simd, C.byref(t), C.byref(cy), C.byref(mhz)),
+             "rslam_k_mfma_f64_probe")
+        return dict(tflops=t.value, cycles_per_mfma=cy.value, clock_mhz=mhz.value)
+
+    def hbm_copy_peak(self, nbytes=1 << 30):
+        v = C.c_double()
+        _chk(lib().rslam_k_hbm_copy_peak(self._h, nbytes, C.byref(v)), "rslam_k_hbm_copy_peak")
+        return v.value

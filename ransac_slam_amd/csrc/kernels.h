@@ -1,0 +1,85 @@
+// kernels.h -- launch interface of the HIP kernels (internal; the public
+// boundary is include/rslam.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "camera_model.h"
+
+namespace rslam {
+
+// d_sel[] slots (device-side frame scalars)
+enum SelSlot {
+    SEL_BEST_HYP = 0, SEL_BEST_SUPPORT = 1, SEL_HYPS_EVALUATED = 2,
+    SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7,
+    SEL_COUNT = 16
+};
+
+constexpr int TG_KC_HOST = 32;   // K granularity of the MFMA tile engine (tile_gemm.h TG_KC)
+
+struct ScoreTables {          // per matched feature (rank j in feature order), m entries each
+    const int32_t* feat;      // feature index
+    const int32_t* off;       // state offset of the feature
+    const uint8_t* type;      // RSLAM_FEAT_*
+    const int32_t* ith;       // state index read as theta (Q1 in compat mode)
+    const int32_t* iph;       // state index read as phi
+    const int32_t* zsrc;      // feature whose z is compared (Q2 in compat mode)
+};
+
+void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
+                    const uint8_t* type, const int32_t* off, double* h, uint8_t* has_h,
+                    uint8_t* vis, double* H13, double* S, double radd);
+
+void launch_innov(hipStream_t s, int m, const int32_t* mfeat, const double* S, const double* z,
+                  const double* h, const uint8_t* has_h, double* wv, int32_t* status);
+
+// out[:, 2c+p] = P[:, cols(list[c])] * H13[list[c]][p]^T for c < count
+void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
+                const int32_t* d_count /* nullable */, const double* H13, const int32_t* off,
+                const uint8_t* type, double* out, long ldo);
+
+void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
+                  const double* wv, const ScoreTables& tab, const double* z, int m, int words,
+                  const int32_t* pos_list /* nullable = identity */, int n_entries,
+                  double threshold, int32_t* sup_out, uint64_t* masks_out);
+
+void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos, int hb, int he,
+                        int32_t* sup);
+
+void launch_select(hipStream_t s, const int32_t* sup, int H, const int32_t* nhyp_table,
+                   int adaptive, int n_hyp_init, int32_t* sel);
+
+// re-score the winning hypothesis and scatter its mask to li[], build list/count
+void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
+                      const double* wv, const ScoreTables& tab, const double* z, int m,
+                      const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
+                      int32_t* list);
+
+void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
+                        const double* S, const double* z, const double* h, double chi2,
+                        uint8_t* hi, int32_t* list, int32_t* sel);
+
+struct SystemDims { int n, NP, RP, ldA; };   // stacked matrix A: rows [0,RP) S | [RP,RP+NP) W | RP+NP: nu^T (+63 pad)
+
+void launch_gather_w(hipStream_t s, const SystemDims& d, const double* W, const int32_t* rank_of,
+                     const int32_t* list, const int32_t* sel, int slot_k, int slot_nblk, double* A);
+void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* list, const int32_t* sel,
+                           int slot_k, int slot_nblk, const double* H13, const int32_t* off,
+                           const uint8_t* type, const double* z, const double* h, double* A);
+void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk,
+                         double* A, double* Linv, int32_t* status_sel);
+void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
+                         const double* A, const double* x_in, double* x_out, double* T, int compat);
+// C = sym(Pin) - Y Y^T on the lower-triangle tile pairs (K from sel[slot_nblk]*64);
+// K == 0: C = Pin exactly (ExtendKF.cpp:635-638 pass-through)
+void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
+                        const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo);
+void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_k, const double* T, double* P);
+
+int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kernels (80 KiB)
+int init_kernel_attributes2();
+void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,
+                    const double* B, long ldb, double beta, double* C, long ldc);
+void launch_mfma_probe(hipStream_t s, int blocks, int iters, double* out, unsigned long long* stamps);
+void launch_copy_probe(hipStream_t s, const double* src, double* dst, long n);
+
+}  // namespace rslam

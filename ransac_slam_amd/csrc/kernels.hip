@@ -1,0 +1,898 @@
+// kernels.hip -- HIP kernels of the 1-point-RANSAC EKF update for gfx950.
+//
+// K1  predict_kernel        h_i, visibility, compact Jacobians, S_i
+// K2  pht_kernel            P*H^T exploiting the 13 structurally non-zero columns (HBM-bound)
+// K3  innov_kernel          w_i = S_i^-1 (z_i - h_i)
+// K4  score_kernel          hypothesis x feature inlier scoring (wave ballot/popcount)
+// K5  select_kernel         replay of the sequential best/adaptive-n_hyp scan
+//     best_mask_kernel      inlier set of the winner -> flags + ordered list
+// K6  gather_w/prepare      stacked system [S; P*H^T; nu^T]
+// K8  chol_diag/panel/trail blocked right-looking Cholesky sweep (MFMA)
+// K9  xupdate/quat          x + Y u, quaternion normalisation
+// K10 rank_update_kernel    P - Y Y^T with symmetrisation (MFMA, lower-triangle tile pairs)
+// K11 quat_cov_kernel       Jnorm congruence on rows/cols 3..6
+// K12 rescue_gate_kernel    chi-square gate of the high-innovation candidates
+#include "kernels.h"
+#include "tile_gemm.h"
+
+namespace rslam {
+
+// ---------------------------------------------------------------------------
+// K1: measurement prediction, Jacobians, innovation covariance per feature
+// Replaces ExtendKF::predict_camera_measurements (ExtendKF.cpp:56-90),
+// Tracking::calculate_derivatives (Tracking.cpp:540-573) and the S_i loop of
+// Tracking::search_IC_matches (Tracking.cpp:39-44) / rescue (:589).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ P, int NP, int L,
+               const uint8_t* __restrict__ type, const int32_t* __restrict__ off,
+               double* h, uint8_t* has_h, uint8_t* vis, double* __restrict__ H13, double* __restrict__ S,
+               double radd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const bool is_id = (type[i] == 0);
+    const int o = off[i];
+    double u, v;
+    const bool visible = predict_feature(cam, x, o, is_id, u, v);
+    bool have = has_h[i] != 0;
+    if (visible) { h[2 * i] = u; h[2 * i + 1] = v; has_h[i] = 1; have = true; }
+    if (vis) vis[i] = visible ? 1 : 0;
+    if (!have) return;
+    const double hu_ = visible ? u : h[2 * i], hv_ = visible ? v : h[2 * i + 1];
+    double Hc[26];
+    feature_jacobian(cam, x, o, is_id, hu_, hv_, Hc);
+#pragma unroll
+    for (int k = 0; k < 26; ++k) H13[26 * i + k] = Hc[k];
+    const int w = is_id ? 13 : 10;
+    double s00 = 0, s10 = 0, s01 = 0, s11 = 0;
+    for (int jj = 0; jj < w; ++jj) {
+        const long cj = col_index(o, jj);
+        double t0 = 0, t1 = 0;
+        for (int kk = 0; kk < w; ++kk) {
+            const double p = P[col_index(o, kk) + cj * NP];
+            t0 += Hc[kk] * p;
+            t1 += Hc[13 + kk] * p;
+        }
+        s00 += t0 * Hc[jj];       s10 += t1 * Hc[jj];
+        s01 += t0 * Hc[13 + jj];  s11 += t1 * Hc[13 + jj];
+    }
+    S[4 * i + 0] = s00 + radd; S[4 * i + 1] = s10; S[4 * i + 2] = s01; S[4 * i + 3] = s11 + radd;
+}
+
+void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
+                    const uint8_t* type, const int32_t* off, double* h, uint8_t* has_h,
+                    uint8_t* vis, double* H13, double* S, double radd)
+{
+    if (L <= 0) return;
+    predict_kernel<<<dim3((L + 63) / 64), dim3(64), 0, s>>>(cam, x, P, NP, L, type, off, h, has_h, vis, H13, S, radd);
+}
+
+// ---------------------------------------------------------------------------
+// K3: w_j = S_j^-1 (z_j - h_j) for every matched feature.  The hypothesis
+// state of Tracking.cpp:420-422 is then xi = x + (P H_j^T) w_j, so the gain
+// K = P H^T S^-1 is never materialised.
+// ---------------------------------------------------------------------------
+__global__ void innov_kernel(int m, const int32_t* __restrict__ mfeat, const double* __restrict__ S,
+                             const double* __restrict__ z, const double* __restrict__ h,
+                             const uint8_t* __restrict__ has_h, double* __restrict__ wv, int32_t* __restrict__ status)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int f = mfeat[j];
+    if (!has_h[f]) {                        // matching() only produces z where h exists (Tracking.cpp:293)
+        atomicMin(status, -7);              // RSLAM_ERR_IC_NOT_VISIBLE
+        wv[2 * j] = 0.0; wv[2 * j + 1] = 0.0;
+        return;
+    }
+    double Si[4] = { S[4 * f], S[4 * f + 1], S[4 * f + 2], S[4 * f + 3] }, Sinv[4];
+    inv2_lu(Si, Sinv);
+    const double n0 = z[2 * f] - h[2 * f], n1 = z[2 * f + 1] - h[2 * f + 1];
+    wv[2 * j]     = Sinv[0] * n0 + Sinv[2] * n1;
+    wv[2 * j + 1] = Sinv[1] * n0 + Sinv[3] * n1;
+}
+
+void launch_innov(hipStream_t s, int m, const int32_t* mfeat, const double* S, const double* z,
+                  const double* h, const uint8_t* has_h, double* wv, int32_t* status)
+{
+    if (m <= 0) return;
+    innov_kernel<<<dim3((m + 63) / 64), dim3(64), 0, s>>>(m, mfeat, S, z, h, has_h, wv, status);
+}
+
+// ---------------------------------------------------------------------------
+// K2: out[:, 2c+p] = sum_k P[:, col_k] * H13[f][p][k] over the 13 (10) non-zero
+// columns of H_f (Tracking.cpp:42,420-421 do this as dense 2 x n products).
+// HBM-bound: every column of P that belongs to a listed feature is streamed once.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ list, int max_count,
+           const int32_t* __restrict__ d_count, const double* __restrict__ H13,
+           const int32_t* __restrict__ off, const uint8_t* __restrict__ type, double* __restrict__ out, long ldo)
+{
+    const int c = blockIdx.y;
+    const int count = d_count ? *d_count : max_count;
+    if (c >= count) return;
+    const int f = list[c];
+    const int o = off[f];
+    const double* Hf = H13 + 26 * (long)f;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= NP) return;
+    const int w = (type[f] == 0) ? 13 : 10;
+    double a0 = 0, a1 = 0;
+    for (int k = 0; k < w; ++k) {
+        const double p = P[row + (long)col_index(o, k) * NP];
+        a0 += p * Hf[k];
+        a1 += p * Hf[13 + k];
+    }
+    out[row + (long)(2 * c) * ldo] = a0;
+    out[row + (long)(2 * c + 1) * ldo] = a1;
+}
+
+void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
+                const int32_t* d_count, const double* H13, const int32_t* off, const uint8_t* type,
+                double* out, long ldo)
+{
+    if (max_count <= 0) return;
+    pht_kernel<<<dim3(NP / 256 + (NP % 256 ? 1 : 0), max_count), dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo);
+}
+
+// ---------------------------------------------------------------------------
+// K4: hypothesis scoring (Tracking.cpp:422-503).  One workgroup per hypothesis,
+// one lane per matched feature.  xi entries are formed on the fly from x and the
+// two P*H^T columns of the hypothesised feature; lanes j, j+1, ... read
+// consecutive 48-byte state groups of those columns (coalesced).
+// ---------------------------------------------------------------------------
+struct HypCtx {
+    double pose[7];
+    double rot[9];     // rotcw = q2r(xi[3:7])^T, column-major
+    double w0, w1;
+    const double* c0;  // P*H^T column for pixel row 0
+    const double* c1;
+};
+
+__device__ __forceinline__ void hyp_setup(const double* __restrict__ x, const double* __restrict__ W, int NP,
+                                          const double* __restrict__ wv, int p, HypCtx& hc)
+{
+    hc.c0 = W + (long)(2 * p) * NP;
+    hc.c1 = hc.c0 + NP;
+    hc.w0 = wv[2 * p]; hc.w1 = wv[2 * p + 1];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) hc.pose[a] = x[a] + (hc.c0[a] * hc.w0 + hc.c1[a] * hc.w1);
+    double Rq[9];
+    q2r(hc.pose + 3, Rq);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) hc.rot[a + 3 * b] = Rq[b + 3 * a];
+}
+
+__device__ __forceinline__ bool score_pair(const Cam& cam, const double* __restrict__ x, const HypCtx& hc,
+                                           const ScoreTables& tab, const double* __restrict__ z, int j, double thr)
+{
+    const int o = tab.off[j];
+#define XI(idx) (x[(idx)] + (hc.c0[(idx)] * hc.w0 + hc.c1[(idx)] * hc.w1))
+    double v[3];
+    const double r0 = XI(o), r1 = XI(o + 1), r2 = XI(o + 2);
+    if (tab.type[j] == 0) {
+        const double th = XI(tab.ith[j]), ph = XI(tab.iph[j]), rho = XI(o + 5);
+        double st, ct, sp, cp;
+        sincos(th, &st, &ct);
+        sincos(ph, &sp, &cp);
+        v[0] = (r0 - hc.pose[0]) * rho + cp * st;
+        v[1] = (r1 - hc.pose[1]) * rho + (-sp);
+        v[2] = (r2 - hc.pose[2]) * rho + cp * ct;
+    } else {
+        v[0] = r0 - hc.pose[0]; v[1] = r1 - hc.pose[1]; v[2] = r2 - hc.pose[2];
+    }
+#undef XI
+    const double h0 = hc.rot[0] * v[0] + hc.rot[3] * v[1] + hc.rot[6] * v[2];
+    const double h1 = hc.rot[1] * v[0] + hc.rot[4] * v[1] + hc.rot[7] * v[2];
+    const double h2 = hc.rot[2] * v[0] + hc.rot[5] * v[1] + hc.rot[8] * v[2];
+    const double fku = cam.f * (1 / cam.dx);           // Tracking.cpp:471: ku on both axes
+    const double ui = fku * (h0 / h2) + cam.Cx;
+    const double vi = fku * (h1 / h2) + cam.Cy;
+    double ud, vd;
+    distort_fm(cam, ui, vi, ud, vd);
+    const int zf = tab.zsrc[j];
+    const double n0 = z[2 * zf] - ud, n1 = z[2 * zf + 1] - vd;
+    return sqrt(n0 * n0 + n1 * n1) < thr;
+}
+
+__global__ void __launch_bounds__(1024)
+score_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
+             const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m, int words,
+             const int32_t* __restrict__ pos_list, double thr, int32_t* __restrict__ sup_out,
+             uint64_t* __restrict__ masks_out)
+{
+    __shared__ int s_count;
+    const int e = blockIdx.x;
+    const int p = pos_list ? pos_list[e] : e;
+    if (threadIdx.x == 0) s_count = 0;
+    HypCtx hc;
+    hyp_setup(x, W, NP, wv, p, hc);
+    __syncthreads();
+    int local = 0;
+    for (int base = 0; base < m; base += blockDim.x) {
+        const int j = base + threadIdx.x;
+        const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);
+        const unsigned long long bal = __ballot(inl);
+        if ((threadIdx.x & 63) == 0) {
+            const int word = j >> 6;
+            if (word < words) {
+                if (masks_out) masks_out[(long)e * words + word] = bal;
+                local += __popcll(bal);
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&s_count, local);
+    __syncthreads();
+    if (threadIdx.x == 0) sup_out[e] = s_count;
+}
+
+static inline int score_block_size(int m)
+{
+    int bs = ((m + 63) / 64) * 64;
+    if (bs < 64) bs = 64;
+    if (bs > 1024) bs = 1024;
+    return bs;
+}
+
+void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
+                  const double* wv, const ScoreTables& tab, const double* z, int m, int words,
+                  const int32_t* pos_list, int n_entries, double threshold, int32_t* sup_out,
+                  uint64_t* masks_out)
+{
+    if (n_entries <= 0 || m <= 0) return;
+    score_kernel<<<dim3(n_entries), dim3(score_block_size(m)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list,
+                                                                   threshold, sup_out, masks_out);
+}
+
+__global__ void map_support_kernel(const int32_t* __restrict__ possup, const int32_t* __restrict__ pos,
+                                   int hb, int he, int32_t* __restrict__ sup)
+{
+    const int i = hb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < he) sup[i] = possup[pos[i]];
+}
+
+void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos, int hb, int he, int32_t* sup)
+{
+    if (he <= hb) return;
+    map_support_kernel<<<dim3((he - hb + 255) / 256), dim3(256), 0, s>>>(possup, pos, hb, he, sup);
+}
+
+// ---------------------------------------------------------------------------
+// K5: replay of the sequential scan of Tracking.cpp:403,507-537 from the
+// complete support list.  Only strict prefix-maximum records can change the
+// loop state, so the block finds the records in parallel (prefix-max scan) and
+// one lane replays the loop over them.
+// ---------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAX_RECORDS = 4096;
+
+__global__ void __launch_bounds__(SEL_THREADS)
+select_kernel(const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table,
+              int adaptive, int n_hyp_init, int32_t* __restrict__ sel)
+{
+    __shared__ int s_max[SEL_THREADS];
+    __shared__ int s_cnt[SEL_THREADS];
+    __shared__ int s_rec[SEL_MAX_RECORDS];
+    const int t = threadIdx.x;
+    const int chunk = (H + SEL_THREADS - 1) / SEL_THREADS;
+    const int lo = t * chunk, hi = min(H, lo + chunk);
+    int mx = 0;
+    for (int i = lo; i < hi; ++i) mx = max(mx, sup[i]);
+    s_max[t] = mx;
+    __syncthreads();
+    for (int d = 1; d < SEL_THREADS; d <<= 1) {        // inclusive prefix max
+        const int other = (t >= d) ? s_max[t - d] : 0;
+        __syncthreads();
+        s_max[t] = max(s_max[t], other);
+        __syncthreads();
+    }
+    int run = (t > 0) ? s_max[t - 1] : 0;              // max of everything before the chunk (supports >= 0)
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) { const int v = sup[i]; if (v > run) { run = v; ++cnt; } }
+    s_cnt[t] = cnt;
+    __syncthreads();
+    for (int d = 1; d < SEL_THREADS; d <<= 1) {        // inclusive prefix sum
+        const int other = (t >= d) ? s_cnt[t - d] : 0;
+        __syncthreads();
+        s_cnt[t] += other;
+        __syncthreads();
+    }
+    int wpos = s_cnt[t] - cnt;
+    run = (t > 0) ? s_max[t - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        const int v = sup[i];
+        if (v > run) { run = v; if (wpos < SEL_MAX_RECORDS) s_rec[wpos] = i; ++wpos; }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int nrec = min(s_cnt[SEL_THREADS - 1], SEL_MAX_RECORDS);
+        int n_hyp = adaptive ? n_hyp_init : H;
+        int best = 0, besti = -1, evaluated = 0, last = 0;
+        bool done = false;
+        for (int k = 0; k < nrec && !done; ++k) {
+            const int i = s_rec[k];
+            if (i >= n_hyp || i >= H) break;           // loop ended before reaching this record
+            best = sup[i]; besti = i; last = i + 1;
+            if (adaptive) {
+                n_hyp = nhyp_table[best];
+                if (n_hyp == 0 || i > n_hyp) { evaluated = i + 1; done = true; }   // the two breaks, :533,:536
+            }
+        }
+        // otherwise the for-condition i < n_hyp ends the loop; iteration `last-1` always ran
+        if (!done) evaluated = max(last, min(n_hyp, H));
+        if (evaluated < 0) evaluated = 0;
+        sel[SEL_BEST_HYP] = besti;
+        sel[SEL_BEST_SUPPORT] = best;
+        sel[SEL_HYPS_EVALUATED] = evaluated;
+    }
+}
+
+void launch_select(hipStream_t s, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive,
+                   int n_hyp_init, int32_t* sel)
+{
+    select_kernel<<<dim3(1), dim3(SEL_THREADS), 0, s>>>(sup, H, nhyp_table, adaptive, n_hyp_init, sel);
+}
+
+// ordered compaction helper: every thread contributes flag; returns its output
+// slot (valid when flag) and advances *running (shared) by the block total.
+__device__ __forceinline__ int block_compact(bool flag, int* s_wave, int* running)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int base = *running;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    int total = 0;
+    for (int w = 0; w < nw; ++w) total += s_wave[w];
+    __syncthreads();
+    if (threadIdx.x == 0) *running += total;
+    __syncthreads();
+    return base + before;
+}
+
+// Winner's inlier set (Tracking.cpp:507-529) -> li[] flags, ordered feature list,
+// k and the number of 64-column blocks of the stacked system.
+__global__ void __launch_bounds__(1024)
+best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
+                 const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
+                 const int32_t* __restrict__ pos, double thr, int L, int32_t* __restrict__ sel,
+                 uint8_t* __restrict__ li, int32_t* __restrict__ list)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_running;
+    if (threadIdx.x == 0) s_running = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) li[i] = 0;
+    __syncthreads();
+    const int best = sel[SEL_BEST_HYP];
+    if (best >= 0) {
+        HypCtx hc;
+        hyp_setup(x, W, NP, wv, pos[best], hc);
+        for (int base = 0; base < m; base += blockDim.x) {
+            const int j = base + threadIdx.x;
+            const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);
+            const int slot = block_compact(inl, s_wave, &s_running);
+            if (inl) { li[tab.feat[j]] = 1; list[slot] = tab.feat[j]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sel[SEL_K_LI] = s_running;
+        sel[SEL_NBLK_LI] = (2 * s_running + 63) / 64;
+    }
+}
+
+void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
+                      const double* wv, const ScoreTables& tab, const double* z, int m,
+                      const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li, int32_t* list)
+{
+    best_mask_kernel<<<dim3(1), dim3(score_block_size(m)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, sel, li, list);
+}
+
+// ---------------------------------------------------------------------------
+// K12: Tracking::rescue_hi_inliers gate (Tracking.cpp:584-595): candidates are
+// individually compatible and not low-innovation inliers; nu' S^-1 nu < chi2.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restrict__ li,
+                   const uint8_t* __restrict__ has_h, const double* __restrict__ S,
+                   const double* __restrict__ z, const double* __restrict__ h, double chi2,
+                   uint8_t* __restrict__ hi, int32_t* __restrict__ list, int32_t* __restrict__ sel)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_running;
+    if (threadIdx.x == 0) s_running = 0;
+    __syncthreads();
+    for (int base = 0; base < L; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        bool flag = false;
+        if (i < L && ic[i] && !li[i] && has_h[i]) {
+            double Si[4] = { S[4 * i], S[4 * i + 1], S[4 * i + 2], S[4 * i + 3] }, Sinv[4];
+            inv2_lu(Si, Sinv);
+            const double n0 = z[2 * i] - h[2 * i], n1 = z[2 * i + 1] - h[2 * i + 1];
+            const double t0 = n0 * Sinv[0] + n1 * Sinv[1];
+            const double t1 = n0 * Sinv[2] + n1 * Sinv[3];
+            flag = (t0 * n0 + t1 * n1) < chi2;
+        }
+        if (i < L) hi[i] = flag ? 1 : 0;
+        const int slot = block_compact(flag, s_wave, &s_running);
+        if (flag) list[slot] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sel[SEL_K_HI] = s_running;
+        sel[SEL_NBLK_HI] = (2 * s_running + 63) / 64;
+    }
+}
+
+void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
+                        const double* S, const double* z, const double* h, double chi2,
+                        uint8_t* hi, int32_t* list, int32_t* sel)
+{
+    int bs = ((L + 63) / 64) * 64;
+    if (bs < 64) bs = 64;
+    if (bs > 1024) bs = 1024;
+    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, hi, list, sel);
+}
+
+// ---------------------------------------------------------------------------
+// K6: stacked system A = [S ; P H^T ; nu^T] of the flagged features
+// (ExtendKF.cpp:565-594 stack z, h, H; :602 S = H P H^T + I).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gather_w_kernel(SystemDims d, const double* __restrict__ W, const int32_t* __restrict__ rank_of,
+                const int32_t* __restrict__ list, const int32_t* __restrict__ sel, int slot_k, int slot_nblk,
+                double* __restrict__ A)
+{
+    const int c = blockIdx.y;
+    if (c >= 64 * sel[slot_nblk]) return;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= d.NP) return;
+    const int k = sel[slot_k];
+    double v = 0.0;
+    if (c < 2 * k) {
+        const int src = 2 * rank_of[list[c >> 1]] + (c & 1);
+        v = W[row + (long)src * d.NP];
+    }
+    A[d.RP + row + (long)c * d.ldA] = v;
+}
+
+void launch_gather_w(hipStream_t s, const SystemDims& d, const double* W, const int32_t* rank_of,
+                     const int32_t* list, const int32_t* sel, int slot_k, int slot_nblk, double* A)
+{
+    if (d.RP <= 0) return;
+    gather_w_kernel<<<dim3((d.NP + 255) / 256, d.RP), dim3(256), 0, s>>>(d, W, rank_of, list, sel, slot_k, slot_nblk, A);
+}
+
+__global__ void __launch_bounds__(256)
+prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int32_t* __restrict__ sel,
+                      int slot_k, int slot_nblk, const double* __restrict__ H13, const int32_t* __restrict__ off,
+                      const uint8_t* __restrict__ type,
+                      const double* __restrict__ z, const double* __restrict__ h, double* __restrict__ A)
+{
+    const int c = blockIdx.x;
+    if (c >= 64 * sel[slot_nblk]) return;
+    const int r = 2 * sel[slot_k];
+    double* col = A + (long)c * d.ldA;
+    const double* wcol = col + d.RP;            // P*H^T column c (already in place)
+    for (int a = threadIdx.x; a < d.RP; a += 256) {
+        double v = (a == c) ? 1.0 : 0.0;        // + R = I (ExtendKF.cpp:594); identity on the padding
+        if (c < r && a < r) {
+            const int fa = list[a >> 1];
+            const double* Hf = H13 + 26 * (long)fa + 13 * (a & 1);
+            const int o = off[fa];
+            const int w = (type[fa] == 0) ? 13 : 10;
+            double sacc = 0;
+            for (int k = 0; k < w; ++k) sacc += Hf[k] * wcol[col_index(o, k)];
+            v += sacc;
+        }
+        col[a] = v;
+    }
+    if (c >= r) for (int a = threadIdx.x; a < d.NP; a += 256) col[d.RP + a] = 0.0;
+    if (threadIdx.x < 64) {
+        double v = 0.0;
+        if (threadIdx.x == 0 && c < r) {
+            const int f = list[c >> 1];
+            v = z[2 * f + (c & 1)] - h[2 * f + (c & 1)];
+        }
+        col[d.RP + d.NP + threadIdx.x] = v;
+    }
+}
+
+void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* list, const int32_t* sel,
+                           int slot_k, int slot_nblk, const double* H13, const int32_t* off,
+                           const uint8_t* type, const double* z, const double* h, double* A)
+{
+    if (d.RP <= 0) return;
+    prepare_system_kernel<<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A);
+}
+
+// ---------------------------------------------------------------------------
+// K8: blocked right-looking Cholesky sweep over the stacked matrix.  After the
+// sweep rows [0,RP) hold L (S = L L^T), rows [RP,RP+NP) hold Y = P H^T L^-T and
+// row RP+NP holds u^T = nu^T L^-T, so that K S K^T = Y Y^T and K nu = Y u
+// (ExtendKF.cpp:603,606,608 use an explicit PartialPivLU inverse of S instead).
+// ---------------------------------------------------------------------------
+constexpr int CD_LD = 65;
+
+__global__ void __launch_bounds__(256)
+chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+                 double* __restrict__ Linv, int32_t* __restrict__ status)
+{
+    if (step >= sel[slot_nblk]) return;
+    __shared__ double T[64 * CD_LD];
+    __shared__ double M[64 * CD_LD];
+    const int t = threadIdx.x;
+    const int i = t & 63, g = t >> 6;
+    double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        // lower triangle is authoritative; mirror it
+        const double v = (i >= c) ? tile[i + (long)c * ldA] : tile[c + (long)i * ldA];
+        T[i * CD_LD + c] = v;
+        M[i * CD_LD + c] = (i == c) ? 1.0 : 0.0;
+    }
+    double* Lout = Linv + (long)step * 64 * 64;
+    bool bad = false;
+    for (int j = 0; j < 64; ++j) {
+        __syncthreads();
+        const double dj = T[j * CD_LD + j];
+        if (!(dj > 0.0)) bad = true;
+        const double rinv = 1.0 / sqrt(dj);
+        const double lij = T[i * CD_LD + j] * rinv;
+        for (int q = 0; q < 16; ++q) {
+            const int c = g + 4 * q;
+            if (c > j) {
+                if (i >= c) T[i * CD_LD + c] -= lij * (T[c * CD_LD + j] * rinv);
+            } else {
+                const double mjc = M[j * CD_LD + c] * rinv;
+                if (i > j) M[i * CD_LD + c] -= lij * mjc;
+                else if (i == j) Lout[j + 64 * c] = mjc;
+            }
+        }
+        if (g == (j & 3)) {
+            if (i >= j) tile[i + (long)j * ldA] = lij;
+            else Lout[i + 64 * j] = 0.0;          // strictly upper part of L^-1
+        }
+    }
+    if (bad && t == 0) atomicMin(status, -6);      // RSLAM_ERR_NOT_SPD
+}
+
+// rows of block b participate in step `step` of a sweep with nblk column blocks?
+__device__ __forceinline__ bool row_block_active(int b, int step, int nblk, int rp_blocks)
+{
+    if (b <= step) return false;
+    if (b < rp_blocks && b >= nblk) return false;   // padding rows of S
+    return true;
+}
+
+// coalesced write of an LDS tile Cs[col][row] to a column-major global tile
+__device__ __forceinline__ void store_tile(const double* Cs, double* C, long ldc)
+{
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        C[row + (long)c * ldc] = Cs[c * TS_LD + row];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+             const double* __restrict__ Linv, int rp_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int nblk = sel[slot_nblk];
+    if (step >= nblk) return;
+    const int b = blockIdx.x;
+    if (!row_block_active(b, step, nblk, rp_blocks)) return;
+    double* tile = A + (long)b * 64 + (long)step * 64 * ldA;
+    d4 acc[2][2];
+    tg_zero(acc);
+    tile_gemm_nt(tile, ldA, Linv + (long)step * 64 * 64, 64, 64, lds, acc);   // X * Linv^T
+    tg_acc_to_lds(acc, lds, 1.0);
+    __syncthreads();
+    store_tile(lds, tile, ldA);
+}
+
+__global__ void __launch_bounds__(256)
+trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+             int rp_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int nblk = sel[slot_nblk];
+    const int i = blockIdx.x, j = blockIdx.y + step + 1;
+    if (step >= nblk || j >= nblk || i < j) return;
+    if (!row_block_active(i, step, nblk, rp_blocks)) return;
+    const double* Ai = A + (long)i * 64 + (long)step * 64 * ldA;
+    const double* Aj = A + (long)j * 64 + (long)step * 64 * ldA;
+    double* C = A + (long)i * 64 + (long)j * 64 * ldA;
+    d4 acc[2][2];
+    tg_zero(acc);
+    tile_gemm_nt(Ai, ldA, Aj, ldA, 64, lds, acc);
+    tg_acc_to_lds(acc, lds, 1.0);
+    __syncthreads();
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        C[row + (long)c * ldA] -= lds[c * TS_LD + row];
+    }
+}
+
+int init_kernel_attributes()
+{
+    const int bytes = (int)(sizeof(double) * TG_LDS_DOUBLES);
+    hipError_t e = hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk,
+                         double* A, double* Linv, int32_t* status_sel)
+{
+    const int rp_blocks = d.RP / 64;
+    const int row_blocks = d.ldA / 64;
+    const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
+    for (int step = 0; step < rp_blocks; ++step) {
+        chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, status_sel);
+        panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
+        if (step + 1 < rp_blocks)
+            trail_kernel<<<dim3(row_blocks, rp_blocks - step - 1), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, rp_blocks);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K9: x_k_k = x + K (z - h) = x + Y u (ExtendKF.cpp:606), then quaternion
+// normalisation and the Jnorm matrix (:613-627; Q6: exponent -3/2 is integer
+// division => 1/|q|^2 in compat mode).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, const double* __restrict__ A,
+               const double* __restrict__ x_in, double* __restrict__ x_out)
+{
+    __shared__ double u[256];
+    const int K = 64 * sel[slot_nblk];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const double* Y = A + d.RP;
+    double acc = 0;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        __syncthreads();
+        if (k0 + threadIdx.x < K) u[threadIdx.x] = A[d.RP + d.NP + (long)(k0 + threadIdx.x) * d.ldA];
+        __syncthreads();
+        const int kn = min(256, K - k0);
+        if (row < d.NP)
+            for (int k = 0; k < kn; ++k) acc += Y[row + (long)(k0 + k) * d.ldA] * u[k];
+    }
+    if (row < d.NP) x_out[row] = x_in[row] + acc;
+}
+
+__global__ void quat_kernel(const int32_t* __restrict__ sel, int slot_k, double* __restrict__ x, double* __restrict__ T,
+                            int compat)
+{
+    if (threadIdx.x != 0 || sel[slot_k] == 0) return;
+    const double r = x[3], qx = x[4], qy = x[5], qz = x[6];
+    const double q2 = r * r + qx * qx + qy * qy + qz * qz;
+    const double nrm = sqrt(q2);
+    x[3] = r / nrm; x[4] = qx / nrm; x[5] = qy / nrm; x[6] = qz / nrm;
+    const double scale = compat ? (1.0 / q2) : (1.0 / (q2 * nrm));
+    const double rows[16] = {
+        qx*qx+qy*qy+qz*qz, -r*qx,            -r*qy,            -r*qz,
+        -qx*r,             r*r+qy*qy+qz*qz,  -qx*qy,           -qx*qz,
+        -qy*r,             -qy*qx,           r*r+qx*qx+qz*qz,  -qy*qz,
+        -qz*r,             -qz*qx,           -qz*qy,           r*r+qx*qx+qy*qy };
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T[i + 4 * j] = scale * rows[4 * i + j];
+}
+
+void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
+                         const double* A, const double* x_in, double* x_out, double* T, int compat)
+{
+    xupdate_kernel<<<dim3((d.NP + 255) / 256), dim3(256), 0, s>>>(d, sel, slot_nblk, A, x_in, x_out);
+    quat_kernel<<<dim3(1), dim3(64), 0, s>>>(sel, slot_k, x_out, T, compat);
+}
+
+// ---------------------------------------------------------------------------
+// K10: covariance rank-r update.  For each lower-triangle tile pair (bi >= bj):
+//   C(bi,bj) = 1/2 (P(bi,bj) + P(bj,bi)^T) - Y_bi Y_bj^T,   C(bj,bi) = C(bi,bj)^T
+// = ExtendKF.cpp:608-609 (P - K S K^T, then 1/2 (P + P^T)) with K S K^T = Y Y^T.
+// Safe in place: a workgroup owns both tiles of its pair.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
+                   const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    // linear index -> (bi >= bj), row-major over the lower triangle
+    const int t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long)bi * (bi + 1) / 2 > t) --bi;
+    while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    (void)nT;
+    const int K = (fixed_k >= 0) ? fixed_k : 64 * sel[slot_nblk];
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const double* Pij = Pin + (long)bi * 64 + (long)bj * 64 * ldp;
+    const double* Pji = Pin + (long)bj * 64 + (long)bi * 64 * ldp;
+    double* Cij = Pout + (long)bi * 64 + (long)bj * 64 * ldo;
+    double* Cji = Pout + (long)bj * 64 + (long)bi * 64 * ldo;
+    if (K == 0) {                                   // update() pass-through, ExtendKF.cpp:635-638
+        if (Pin != Pout) {
+            for (int q = 0; q < 16; ++q) {
+                const int c = g + 4 * q;
+                Cij[row + (long)c * ldo] = Pij[row + (long)c * ldp];
+                if (bi != bj) Cji[row + (long)c * ldo] = Pji[row + (long)c * ldp];
+            }
+        }
+        return;
+    }
+    d4 acc[2][2];
+    tg_zero(acc);
+    tile_gemm_nt(Y + (long)bi * 64, ldy, Y + (long)bj * 64, ldy, K, lds, acc);
+    double* Cs = lds;
+    double* Ts = lds + TS_DOUBLES;
+    tg_acc_to_lds(acc, Cs, 1.0);
+    for (int q = 0; q < 16; ++q) {                  // tile (bj,bi), element (row, c) -> Ts[c][row]
+        const int c = g + 4 * q;
+        Ts[c * TS_LD + row] = Pji[row + (long)c * ldp];
+    }
+    __syncthreads();
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        const double pij = Pij[row + (long)c * ldp];
+        const double pji = Ts[row * TS_LD + c];     // P(bj,bi)[c, row]
+        const double o = (0.5 * pij + 0.5 * pji) - Cs[c * TS_LD + row];
+        Cij[row + (long)c * ldo] = o;
+        Cs[c * TS_LD + row] = o;
+    }
+    __syncthreads();
+    if (bi != bj) {
+        for (int q = 0; q < 16; ++q) {
+            const int c = g + 4 * q;
+            Cji[row + (long)c * ldo] = Cs[row * TS_LD + c];
+        }
+    }
+}
+
+int init_kernel_attributes2();
+void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
+                        const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo)
+{
+    const int nT = NP / 64;
+    const int tiles = nT * (nT + 1) / 2;
+    if (tiles <= 0) return;
+    rank_update_kernel<<<dim3(tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
+                                                                                  fixed_k, Pout, ldo);
+}
+
+// ---------------------------------------------------------------------------
+// K11: Jnorm congruence on rows/columns 3..6 (ExtendKF.cpp:629-634).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+quat_cov_kernel(int n, int NP, const int32_t* __restrict__ sel, int slot_k, const double* __restrict__ T,
+                double* __restrict__ P)
+{
+    if (sel[slot_k] == 0) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    if (j >= 3 && j < 7) {
+        if (j != 3) return;
+        double cb[4][4], out[4][4];                 // cb = J * P44 ; out = cb * J^T
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 4; ++c) {
+                double sacc = 0;
+                for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * P[(3 + k) + (long)(3 + c) * NP];
+                cb[i][c] = sacc;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 4; ++c) {
+                double sacc = 0;
+                for (int k = 0; k < 4; ++k) sacc += cb[i][k] * T[c + 4 * k];
+                out[i][c] = sacc;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 4; ++c) P[(3 + i) + (long)(3 + c) * NP] = out[i][c];
+        return;
+    }
+    double rb[4];
+    for (int i = 0; i < 4; ++i) {
+        double sacc = 0;
+        for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * P[(3 + k) + (long)j * NP];
+        rb[i] = sacc;
+    }
+    for (int i = 0; i < 4; ++i) {
+        P[(3 + i) + (long)j * NP] = rb[i];
+        P[j + (long)(3 + i) * NP] = rb[i];
+    }
+}
+
+void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_k, const double* T, double* P)
+{
+    quat_cov_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(n, NP, sel, slot_k, T, P);
+}
+
+// ---------------------------------------------------------------------------
+// Generic dense NT GEMM on the same MFMA tile engine (dense form of P*H^T).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gemm_nt_kernel(int K, double alpha, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+               double beta, double* __restrict__ C, long ldc)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    d4 acc[2][2];
+    tg_zero(acc);
+    tile_gemm_nt(A + (long)bi * 64, lda, B + (long)bj * 64, ldb, K, lds, acc);
+    tg_acc_to_lds(acc, lds, alpha);
+    __syncthreads();
+    double* Ct = C + (long)bi * 64 + (long)bj * 64 * ldc;
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        const double prev = (beta != 0.0) ? beta * Ct[row + (long)c * ldc] : 0.0;
+        Ct[row + (long)c * ldc] = lds[c * TS_LD + row] + prev;
+    }
+}
+
+void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,
+                    const double* B, long ldb, double beta, double* C, long ldc)
+{
+    gemm_nt_kernel<<<dim3(M / 64, N / 64), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(K, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+int init_kernel_attributes2()
+{
+    const int bytes = (int)(sizeof(double) * TG_LDS_DOUBLES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return (int)e;
+}
+
+// ---------------------------------------------------------------------------
+// Probes: FP64 MFMA issue rate and streaming-copy bandwidth of this device.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mfma_probe_kernel(int iters, double* out, unsigned long long* stamps)
+{
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    const d4 sum = c0 + c1 + c2 + c3;
+    asm volatile("" :: "v"(sum[0]));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (sum[0] == -1.0) out[blockIdx.x * 256 + threadIdx.x] = sum[1] + sum[2] + sum[3];
+    if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
+}
+
+void launch_mfma_probe(hipStream_t s, int blocks, int iters, double* out, unsigned long long* stamps)
+{
+    mfma_probe_kernel<<<dim3(blocks), dim3(256), 0, s>>>(iters, out, stamps);
+}
+
+__global__ void __launch_bounds__(256)
+copy_probe_kernel(const d2* __restrict__ src, d2* __restrict__ dst, long n2)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+void launch_copy_probe(hipStream_t s, const double* src, double* dst, long n)
+{
+    copy_probe_kernel<<<dim3(2048), dim3(256), 0, s>>>(reinterpret_cast<const d2*>(src), reinterpret_cast<d2*>(dst), n / 2);
+}
+
+}  // namespace rslam

@@ -1,0 +1,740 @@
+// rslam_api.hip -- context management and the C ABI of include/rslam.h.
+//
+// Data layout in HBM (all FP64, column-major):
+//   x_pred[NP], P_pred[NP x NP]        prior, NP = round_up(n, 64), zero padded
+//   H13[L][2][13]                      compact Jacobians (7 pose + 6 feature columns)
+//   W[NP x 2m]                         P H^T of the m matched features (2 columns each)
+//   A[(RP + NP + 64) x RP]             stacked system [S; P H^T; nu^T] of one update,
+//                                      RP = round_up(2m, 64); becomes [L; Y; u^T]
+//   P[NP x NP]                         posterior covariance (LI update out of place,
+//                                      HI update in place)
+// Frame scalars (best hypothesis, inlier counts, block counts, status) live in
+// d_sel[] on the device: no kernel launch depends on a host read-back, so a whole
+// frame is one stream-ordered (or hipGraph-replayed) launch sequence.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/rslam.h"
+#include "kernels.h"
+
+using namespace rslam;
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx_last_hip_error = (int)e_; return RSLAM_ERR_HIP; } } while (0)
+static thread_local int ctx_last_hip_error = 0;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (n == 0) n = 1;
+        if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) return -1;
+        cap = n;
+        return 1;     // (re)allocated
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+enum { EV_START = 0, EV_PREDICT, EV_PHT, EV_SCORE, EV_SELECT, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0,
+       EV_LI_RANK1, EV_LI_END, EV_RESCUE, EV_HI_END, EV_COUNT };
+
+}  // namespace
+
+struct rslam_ctx {
+    rslam_config cfg;
+    Cam cam;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // frame shape
+    int n = 0, NP = 0, L = 0, m = 0, H = 0, words = 0, RP = 0, ldA = 0;
+    int m_id = 0, m_euc = 0;
+    bool have_state = false, have_meas = false, predicted = false, pht_done = false, dedup_done = false;
+    std::vector<uint8_t> h_type, h_vis;
+    std::vector<int32_t> h_off;
+    // device buffers
+    DevBuf<uint8_t> d_type, d_vis, d_hash, d_hash2, d_ic, d_li, d_hi, d_mtype;
+    DevBuf<int32_t> d_off, d_mfeat, d_moff, d_mith, d_miph, d_mzsrc, d_rank_of, d_pos, d_nhyp,
+                    d_sup, d_possup, d_lilist, d_hilist, d_sel;
+    DevBuf<uint64_t> d_masks, d_posmask;
+    DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Linv,
+                   d_x1, d_x2, d_P, d_T, d_probe;
+    // timing
+    int timing = 0;
+    hipEvent_t ev[EV_COUNT];
+    bool ev_ok = false;
+    rslam_stage_times times;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_valid = false;
+    int attr_init = 0;
+};
+
+static void invalidate_graph(rslam_ctx* c)
+{
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    c->graph_valid = false;
+}
+
+extern "C" const char* rslam_version(void) { return "rslam-hip 0.1 (gfx950)"; }
+
+extern "C" const char* rslam_error_string(int code)
+{
+    switch (code) {
+    case RSLAM_OK: return "ok";
+    case RSLAM_ERR_ARG: return "invalid argument";
+    case RSLAM_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case RSLAM_ERR_HIP: return "HIP runtime error";
+    case RSLAM_ERR_STATE: return "call order violated";
+    case RSLAM_ERR_REF_ASSERT: return "input on which the reference hits an Eigen assertion (Tracking.cpp:498)";
+    case RSLAM_ERR_NOT_SPD: return "innovation covariance not positive definite";
+    case RSLAM_ERR_IC_NOT_VISIBLE: return "individually compatible flag on a feature that is not visible";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out)
+{
+    if (!cfg || !out) return RSLAM_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RSLAM_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return RSLAM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RSLAM_ERR_NO_DEVICE;
+    rslam_ctx* c = new rslam_ctx();
+    c->cfg = *cfg;
+    c->cam.k1 = cfg->cam.k1; c->cam.k2 = cfg->cam.k2; c->cam.Cx = cfg->cam.Cx; c->cam.Cy = cfg->cam.Cy;
+    c->cam.f = cfg->cam.f; c->cam.dx = cfg->cam.dx; c->cam.dy = cfg->cam.dy;
+    c->cam.nRows = cfg->cam.nRows; c->cam.nCols = cfg->cam.nCols;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RSLAM_ERR_HIP; }
+    c->stream = c->own_stream;
+    if (init_kernel_attributes() != 0 || init_kernel_attributes2() != 0) { (void)hipStreamDestroy(c->own_stream); delete c; return RSLAM_ERR_HIP; }
+    bool ok = true;
+    for (int i = 0; i < EV_COUNT; ++i) ok = ok && (hipEventCreate(&c->ev[i]) == hipSuccess);
+    c->ev_ok = ok;
+    memset(&c->times, 0, sizeof(c->times));
+    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0) { delete c; return RSLAM_ERR_HIP; }
+    *out = c;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_destroy(rslam_ctx* c)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    invalidate_graph(c);
+    c->d_type.release(); c->d_vis.release(); c->d_hash.release(); c->d_hash2.release(); c->d_ic.release();
+    c->d_li.release(); c->d_hi.release(); c->d_mtype.release();
+    c->d_off.release(); c->d_mfeat.release(); c->d_moff.release(); c->d_mith.release(); c->d_miph.release();
+    c->d_mzsrc.release(); c->d_rank_of.release(); c->d_pos.release(); c->d_nhyp.release(); c->d_sup.release();
+    c->d_possup.release(); c->d_lilist.release(); c->d_hilist.release(); c->d_sel.release();
+    c->d_masks.release(); c->d_posmask.release();
+    c->d_xpred.release(); c->d_Ppred.release(); c->d_h.release(); c->d_h2.release(); c->d_H13.release();
+    c->d_H13b.release(); c->d_S.release(); c->d_S2.release(); c->d_z.release(); c->d_wv.release();
+    c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
+    c->d_P.release(); c->d_T.release(); c->d_probe.release();
+    if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_set_stream(rslam_ctx* c, void* hip_stream)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    invalidate_graph(c);
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_enable_timing(rslam_ctx* c, int on)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    c->timing = on ? 1 : 0;
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// uploads
+// ------------------------------------------------------------------------
+static int upload_state(rslam_ctx* c, const rslam_layout* lay, const double* x_pred, const double* P_pred)
+{
+    if (!lay || !x_pred || !P_pred || lay->n < 13 || lay->L < 0 || (lay->L > 0 && (!lay->type || !lay->offset)))
+        return RSLAM_ERR_ARG;
+    const int n = lay->n, L = lay->L;
+    for (int i = 0; i < L; ++i) {
+        if (lay->type[i] > 1) return RSLAM_ERR_ARG;
+        const int w = lay->type[i] == RSLAM_FEAT_INVERSE_DEPTH ? 6 : 3;
+        if (lay->offset[i] < 13 || lay->offset[i] + w > n) return RSLAM_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int NP = round_up(n, 64);
+    if (n != c->n || L != c->L) invalidate_graph(c);
+    c->n = n; c->NP = NP; c->L = L;
+    c->h_type.assign(lay->type, lay->type + L);
+    c->h_off.assign(lay->offset, lay->offset + L);
+    c->h_vis.assign((size_t)L, 0);
+    int re = 0, r;
+#define ENS(buf, cnt) do { r = (buf).ensure(cnt); if (r < 0) return RSLAM_ERR_HIP; re |= r; } while (0)
+    ENS(c->d_type, L); ENS(c->d_off, L); ENS(c->d_vis, L); ENS(c->d_hash, L); ENS(c->d_hash2, L);
+    ENS(c->d_ic, L); ENS(c->d_li, L); ENS(c->d_hi, L); ENS(c->d_rank_of, L);
+    ENS(c->d_xpred, NP); ENS(c->d_x1, NP); ENS(c->d_x2, NP);
+    ENS(c->d_Ppred, (size_t)NP * NP); ENS(c->d_P, (size_t)NP * NP);
+    ENS(c->d_h, 2 * (size_t)L); ENS(c->d_h2, 2 * (size_t)L); ENS(c->d_H13, 26 * (size_t)L); ENS(c->d_H13b, 26 * (size_t)L);
+    ENS(c->d_S, 4 * (size_t)L); ENS(c->d_S2, 4 * (size_t)L); ENS(c->d_z, 2 * (size_t)L);
+    if (re) invalidate_graph(c);
+    hipStream_t s = c->stream;
+    if (L > 0) {
+        HIPCHK(hipMemcpyAsync(c->d_type.p, lay->type, L, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->d_off.p, lay->offset, sizeof(int32_t) * L, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemsetAsync(c->d_xpred.p, 0, sizeof(double) * NP, s));
+    HIPCHK(hipMemcpyAsync(c->d_xpred.p, x_pred, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    if (NP != n) HIPCHK(hipMemsetAsync(c->d_Ppred.p, 0, sizeof(double) * (size_t)NP * NP, s));
+    HIPCHK(hipMemcpy2DAsync(c->d_Ppred.p, sizeof(double) * NP, P_pred, sizeof(double) * n, sizeof(double) * n, n,
+                            hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false;
+    return RSLAM_OK;
+}
+
+// Builds the gather tables that replace Converter::find/select/repmat
+// (Converter.cpp:210-287 as used at Tracking.cpp:361-397,413-415,443-448).
+static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic, const double* draws, int n_draws,
+                               bool check_visible)
+{
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    if (!z || !ic || (n_draws > 0 && !draws) || n_draws < 0) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int L = c->L;
+    std::vector<int32_t> mfeat, moff, mith, miph, mzsrc, rank_of((size_t)L, -1), id_list, euc_list;
+    std::vector<uint8_t> mtype;
+    for (int i = 0; i < L; ++i) {
+        if (!ic[i]) continue;
+        if (check_visible && !c->h_vis[i]) return RSLAM_ERR_IC_NOT_VISIBLE;   // matching() needs h, Tracking.cpp:293
+        rank_of[i] = (int32_t)mfeat.size();
+        mfeat.push_back(i);
+        (c->h_type[i] == RSLAM_FEAT_INVERSE_DEPTH ? id_list : euc_list).push_back(i);
+    }
+    const int m = (int)mfeat.size(), m_id = (int)id_list.size(), m_euc = (int)euc_list.size();
+    if (m >= 4096) return RSLAM_ERR_ARG;
+    if (c->cfg.compat && m_euc > 0 && m_euc != m_id) return RSLAM_ERR_REF_ASSERT;     // Q2
+    moff.resize(m); mith.resize(m); miph.resize(m); mzsrc.resize(m); mtype.resize(m);
+    int jj = 0, je = 0;
+    for (int j = 0; j < m; ++j) {
+        const int f = mfeat[j];
+        moff[j] = c->h_off[f]; mtype[j] = c->h_type[f];
+        if (mtype[j] == RSLAM_FEAT_INVERSE_DEPTH) {
+            if (c->cfg.compat) {        // Q1: anglesi mapped onto ri_v (Tracking.cpp:448)
+                const int a = 2 * jj, b = 2 * jj + 1;
+                mith[j] = c->h_off[id_list[a / 3]] + a % 3;
+                miph[j] = c->h_off[id_list[b / 3]] + b % 3;
+            } else { mith[j] = moff[j] + 3; miph[j] = moff[j] + 4; }
+            mzsrc[j] = f; ++jj;
+        } else {
+            mith[j] = miph[j] = 0;
+            mzsrc[j] = c->cfg.compat ? id_list[je] : f;   // Q2: z_id used for Cartesian residuals (Tracking.cpp:498)
+            ++je;
+        }
+    }
+    const int H = n_draws;
+    const int words = (m + 63) / 64;
+    const int RP = round_up(2 * m, 64);
+    const int ldA = RP + c->NP + 64;
+    if (m != c->m || H != c->H || RP != c->RP) invalidate_graph(c);
+    c->m = m; c->H = H; c->words = words; c->RP = RP; c->ldA = ldA; c->m_id = m_id; c->m_euc = m_euc;
+    // hypothesis -> matched rank: floor(t * N)-th IC feature (Tracking.cpp:412-415; Q3 guard)
+    std::vector<int32_t> pos((size_t)H, 0);
+    for (int i = 0; i < H; ++i) {
+        int p = (int)floor(draws[i] * (double)m);
+        if (p >= m) p = m - 1;
+        if (p < 0) p = 0;
+        pos[i] = p;
+    }
+    // n_hyp after an improvement, tabulated with the host libm (Tracking.cpp:531-532)
+    std::vector<int32_t> nhyp((size_t)m + 1, 0);
+    for (int sidx = 1; sidx <= m; ++sidx) {
+        const double epsilon = 1 - ((double)sidx / (double)m);
+        nhyp[sidx] = (int32_t)ceil((log(1 - c->cfg.p_success)) / (log(1 - (1 - epsilon))));
+    }
+    int re = 0, r;
+    ENS(c->d_mfeat, m); ENS(c->d_moff, m); ENS(c->d_mith, m); ENS(c->d_miph, m); ENS(c->d_mzsrc, m); ENS(c->d_mtype, m);
+    ENS(c->d_pos, H); ENS(c->d_nhyp, (size_t)m + 1); ENS(c->d_sup, H); ENS(c->d_possup, m);
+    ENS(c->d_masks, (size_t)H * (words ? words : 1)); ENS(c->d_posmask, (size_t)m * (words ? words : 1));
+    ENS(c->d_lilist, m); ENS(c->d_hilist, m);
+    ENS(c->d_wv, 2 * (size_t)m); ENS(c->d_W, (size_t)c->NP * 2 * (m ? m : 1));
+    ENS(c->d_A, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Linv, (size_t)64 * 64 * (RP / 64 ? RP / 64 : 1));
+    if (re) invalidate_graph(c);
+#undef ENS
+    hipStream_t s = c->stream;
+#define H2D(dst, vec) do { if (!(vec).empty()) HIPCHK(hipMemcpyAsync((dst).p, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, s)); } while (0)
+    H2D(c->d_mfeat, mfeat); H2D(c->d_moff, moff); H2D(c->d_mith, mith); H2D(c->d_miph, miph); H2D(c->d_mzsrc, mzsrc);
+    H2D(c->d_mtype, mtype); H2D(c->d_rank_of, rank_of); H2D(c->d_pos, pos); H2D(c->d_nhyp, nhyp);
+#undef H2D
+    if (L > 0) {
+        HIPCHK(hipMemcpyAsync(c->d_z.p, z, sizeof(double) * 2 * L, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->d_ic.p, ic, L, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    c->have_meas = true; c->pht_done = false; c->dedup_done = false;
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// stage enqueue
+// ------------------------------------------------------------------------
+static inline void mark(rslam_ctx* c, int ev) { if (c->timing && c->ev_ok) (void)hipEventRecord(c->ev[ev], c->stream); }
+
+static ScoreTables tables(rslam_ctx* c)
+{
+    ScoreTables t;
+    t.feat = c->d_mfeat.p; t.off = c->d_moff.p; t.type = c->d_mtype.p;
+    t.ith = c->d_mith.p; t.iph = c->d_miph.p; t.zsrc = c->d_mzsrc.p;
+    return t;
+}
+
+static int enqueue_predict(rslam_ctx* c)
+{
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    hipStream_t s = c->stream;
+    mark(c, EV_START);
+    HIPCHK(hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, s));
+    if (c->L > 0) HIPCHK(hipMemsetAsync(c->d_hash.p, 0, c->L, s));     // Map.cpp:51 resets h every frame
+    launch_predict(s, c->cam, c->d_xpred.p, c->d_Ppred.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
+                   c->d_vis.p, c->d_H13.p, c->d_S.p, 1.0 /* features_info[i].R = I, Map.cpp:310 */);
+    mark(c, EV_PREDICT);
+    c->predicted = true; c->pht_done = false; c->dedup_done = false;
+    return RSLAM_OK;
+}
+
+static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
+{
+    if (!c->predicted || !c->have_meas) return RSLAM_ERR_STATE;
+    if (hb < 0 || he > c->H || hb > he || !d_sup) return RSLAM_ERR_ARG;
+    hipStream_t s = c->stream;
+    if (!c->pht_done) {
+        launch_innov(s, c->m, c->d_mfeat.p, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
+        launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
+                   c->d_W.p, c->NP);
+        c->pht_done = true;
+    }
+    mark(c, EV_PHT);
+    if (c->m > 0 && he > hb) {
+        if (c->cfg.dedup) {
+            if (!c->dedup_done) {
+                launch_score(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->words,
+                             nullptr, c->m, c->cfg.sigma_z, c->d_possup.p, c->d_posmask.p);
+                c->dedup_done = true;
+            }
+            launch_map_support(s, c->d_possup.p, c->d_pos.p, hb, he, d_sup);
+        } else {
+            launch_score(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->words,
+                         c->d_pos.p + hb, he - hb, c->cfg.sigma_z, d_sup + hb, c->d_masks.p + (size_t)hb * c->words);
+        }
+    } else if (he > hb) {
+        HIPCHK(hipMemsetAsync(d_sup + hb, 0, sizeof(int32_t) * (he - hb), s));
+    }
+    mark(c, EV_SCORE);
+    return RSLAM_OK;
+}
+
+static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, const double* H13,
+                              const double* z_h, const double* x_in, double* x_out, const double* Pin, double* Pout,
+                              int ev_f0, int ev_f1, int ev_r0, int ev_r1)
+{
+    hipStream_t s = c->stream;
+    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
+    int32_t* sel = c->d_sel.p;
+    launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p);
+    if (ev_f0 >= 0) mark(c, ev_f0);
+    launch_factor_sweep(s, d, sel, slot_nblk, c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
+    if (ev_f1 >= 0) mark(c, ev_f1);
+    if (c->RP > 0) {
+        launch_state_update(s, d, sel, slot_k, slot_nblk, c->d_A.p, x_in, x_out, c->d_T.p, c->cfg.compat);
+    } else {
+        HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
+    }
+    if (ev_r0 >= 0) mark(c, ev_r0);
+    launch_rank_update(s, c->NP, Pin, c->NP, c->d_A.p + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP);
+    if (ev_r1 >= 0) mark(c, ev_r1);
+    if (c->RP > 0) launch_quat_cov(s, c->n, c->NP, sel, slot_k, c->d_T.p, Pout);
+    return RSLAM_OK;
+}
+
+static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
+{
+    if (!c->predicted || !c->have_meas) return RSLAM_ERR_STATE;
+    if (!d_sup) return RSLAM_ERR_ARG;
+    hipStream_t s = c->stream;
+    int32_t* sel = c->d_sel.p;
+    if (!c->pht_done) {   // update without a local score pass (supports came from elsewhere)
+        launch_innov(s, c->m, c->d_mfeat.p, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
+        launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
+                   c->d_W.p, c->NP);
+        c->pht_done = true;
+    }
+    // K5 consensus (Tracking.cpp:507-537)
+    launch_select(s, d_sup, c->H, c->d_nhyp.p, c->cfg.adaptive, c->cfg.n_hyp_init, sel);
+    launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
+                     c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p);
+    mark(c, EV_SELECT);
+    // low-innovation update (ExtendKF.cpp:559-596)
+    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
+    launch_gather_w(s, d, c->d_W.p, c->d_rank_of.p, c->d_lilist.p, sel, SEL_K_LI, SEL_NBLK_LI, c->d_A.p);
+    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
+                                c->d_Ppred.p, c->d_P.p, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0, EV_LI_RANK1);
+    if (rc) return rc;
+    mark(c, EV_LI_END);
+    // rescue (Tracking.cpp:574-597): re-predict at x_k_k; invisible features keep their stale h
+    if (c->L > 0) {
+        HIPCHK(hipMemcpyAsync(c->d_h2.p, c->d_h.p, sizeof(double) * 2 * c->L, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->d_hash2.p, c->d_hash.p, c->L, hipMemcpyDeviceToDevice, s));
+    }
+    launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h2.p, c->d_hash2.p, nullptr,
+                   c->d_H13b.p, c->d_S2.p, c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */);
+    launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
+                       c->d_hi.p, c->d_hilist.p, sel);
+    mark(c, EV_RESCUE);
+    // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
+    if (c->RP > 0)
+        launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
+                   c->d_A.p + c->RP, c->ldA);
+    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
+                            c->d_P.p, c->d_P.p, -1, -1, -1, -1);
+    if (rc) return rc;
+    mark(c, EV_HI_END);
+    return RSLAM_OK;
+}
+
+static int read_status(rslam_ctx* c, int32_t* sel_host)
+{
+    int32_t sel[SEL_COUNT];
+    HIPCHK(hipMemcpyAsync(sel, c->d_sel.p, sizeof(sel), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    if (sel_host) memcpy(sel_host, sel, sizeof(sel));
+    return sel[SEL_STATUS];
+}
+
+static void collect_times(rslam_ctx* c)
+{
+    if (!c->timing || !c->ev_ok) return;
+    auto el = [&](int a, int b) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return 0.0; return (double)ms * 1e3; };
+    rslam_stage_times& t = c->times;
+    t.predict_us = el(EV_START, EV_PREDICT);
+    t.pht_us = el(EV_PREDICT, EV_PHT);
+    t.score_us = el(EV_PHT, EV_SCORE);
+    t.select_us = el(EV_SCORE, EV_SELECT);
+    t.update_li_us = el(EV_SELECT, EV_LI_END);
+    t.rescue_us = el(EV_LI_END, EV_RESCUE);
+    t.update_hi_us = el(EV_RESCUE, EV_HI_END);
+    t.rank_update_us = el(EV_LI_RANK0, EV_LI_RANK1);
+    t.factor_us = el(EV_LI_FACTOR0, EV_LI_FACTOR1);
+    t.total_us = el(EV_START, EV_HI_END);
+}
+
+// ------------------------------------------------------------------------
+// drop-in API
+// ------------------------------------------------------------------------
+extern "C" int rslam_predict(rslam_ctx* c, const rslam_layout* layout, const double* x_pred, const double* P_pred,
+                             double* h, uint8_t* visible, double* S)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    int rc = upload_state(c, layout, x_pred, P_pred);
+    if (rc) return rc;
+    rc = enqueue_predict(c);
+    if (rc) return rc;
+    const int L = c->L;
+    std::vector<double> hh(2 * (size_t)L + 1), SS(4 * (size_t)L + 1);
+    if (L > 0) {
+        HIPCHK(hipMemcpyAsync(hh.data(), c->d_h.p, sizeof(double) * 2 * L, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(SS.data(), c->d_S.p, sizeof(double) * 4 * L, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_vis.data(), c->d_vis.p, L, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < L; ++i) {
+        if (visible) visible[i] = c->h_vis[i];
+        if (!c->h_vis[i]) continue;
+        if (h) { h[2 * i] = hh[2 * i]; h[2 * i + 1] = hh[2 * i + 1]; }
+        if (S) memcpy(S + 4 * i, SS.data() + 4 * i, sizeof(double) * 4);
+    }
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
+{
+    if (!c || !P) return RSLAM_ERR_ARG;
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy2DAsync(P, sizeof(double) * c->n, c->d_P.p, sizeof(double) * c->NP, sizeof(double) * c->n, c->n,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_fetch_state(rslam_ctx* c, double* x)
+{
+    if (!c || !x) return RSLAM_ERR_ARG;
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(x, c->d_x2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_fetch_results(rslam_ctx* c, double* x_new, uint8_t* li, uint8_t* hi, int32_t* best_hyp,
+                                   int32_t* best_support, int32_t* hyps_evaluated, int32_t* n_li, int32_t* n_hi)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    int32_t sel[SEL_COUNT];
+    if (x_new) HIPCHK(hipMemcpyAsync(x_new, c->d_x2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    if (li && c->L) HIPCHK(hipMemcpyAsync(li, c->d_li.p, c->L, hipMemcpyDeviceToHost, c->stream));
+    if (hi && c->L) HIPCHK(hipMemcpyAsync(hi, c->d_hi.p, c->L, hipMemcpyDeviceToHost, c->stream));
+    const int status = read_status(c, sel);
+    collect_times(c);
+    if (best_hyp) *best_hyp = sel[SEL_BEST_HYP];
+    if (best_support) *best_support = sel[SEL_BEST_SUPPORT];
+    if (hyps_evaluated) *hyps_evaluated = sel[SEL_HYPS_EVALUATED];
+    if (n_li) *n_li = sel[SEL_K_LI];
+    if (n_hi) *n_hi = sel[SEL_K_HI];
+    return status;
+}
+
+extern "C" int rslam_ransac_update(rslam_ctx* c, const double* z, const uint8_t* ic, const double* draws,
+                                   int32_t n_draws, double* x_new, double* P_new, uint8_t* li, uint8_t* hi,
+                                   int32_t* best_hyp, int32_t* best_support, int32_t* hyps_evaluated)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->predicted) return RSLAM_ERR_STATE;
+    int rc = upload_measurements(c, z, ic, draws, n_draws, true);
+    if (rc) return rc;
+    rc = enqueue_score(c, 0, c->H, c->d_sup.p);
+    if (rc) return rc;
+    rc = enqueue_update(c, c->d_sup.p);
+    if (rc) return rc;
+    rc = rslam_fetch_results(c, x_new, li, hi, best_hyp, best_support, hyps_evaluated, nullptr, nullptr);
+    if (rc) return rc;
+    if (P_new) return rslam_fetch_cov(c, P_new);
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_timings(rslam_ctx* c, rslam_stage_times* out)
+{
+    if (!c || !out) return RSLAM_ERR_ARG;
+    *out = c->times;
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// resident API
+// ------------------------------------------------------------------------
+extern "C" int rslam_load_frame(rslam_ctx* c, const rslam_layout* layout, const double* x_pred, const double* P_pred,
+                                const double* z, const uint8_t* ic, const double* draws, int32_t n_draws)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    int rc = upload_state(c, layout, x_pred, P_pred);
+    if (rc) return rc;
+    return upload_measurements(c, z, ic, draws, n_draws, false);
+}
+
+extern "C" int rslam_step_predict(rslam_ctx* c)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return enqueue_predict(c);
+}
+
+extern "C" int rslam_step_score(rslam_ctx* c, int32_t hyp_begin, int32_t hyp_end, int32_t* d_supports)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return enqueue_score(c, hyp_begin, hyp_end, d_supports);
+}
+
+extern "C" int rslam_step_update(rslam_ctx* c, const int32_t* d_supports)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return enqueue_update(c, d_supports);
+}
+
+static int enqueue_frame(rslam_ctx* c)
+{
+    int rc = enqueue_predict(c);
+    if (rc) return rc;
+    rc = enqueue_score(c, 0, c->H, c->d_sup.p);
+    if (rc) return rc;
+    return enqueue_update(c, c->d_sup.p);
+}
+
+extern "C" int rslam_step_frame(rslam_ctx* c, int32_t use_graph)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_state || !c->have_meas) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    if (!use_graph || c->timing) return enqueue_frame(c);
+    if (!c->graph_valid) {
+        invalidate_graph(c);
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_frame(c);
+        hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+        if (rc) { if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; } return rc; }
+        if (e != hipSuccess || !c->graph) { ctx_last_hip_error = (int)e; return RSLAM_ERR_HIP; }
+        HIPCHK(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        c->graph_valid = true;
+    }
+    HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+    c->predicted = true; c->pht_done = true;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_sync(rslam_ctx* c)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int status = read_status(c, nullptr);
+    collect_times(c);
+    return status;
+}
+
+extern "C" int rslam_fetch_prediction(rslam_ctx* c, double* h, uint8_t* visible, double* S)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->predicted) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const int L = c->L;
+    if (L > 0) {
+        if (h) HIPCHK(hipMemcpyAsync(h, c->d_h.p, sizeof(double) * 2 * L, hipMemcpyDeviceToHost, c->stream));
+        if (S) HIPCHK(hipMemcpyAsync(S, c->d_S.p, sizeof(double) * 4 * L, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_vis.data(), c->d_vis.p, L, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (visible && L > 0) memcpy(visible, c->h_vis.data(), L);
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_fetch_supports(rslam_ctx* c, int32_t* supports, uint64_t* masks, int32_t* n_mask_words)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_meas) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    if (n_mask_words) *n_mask_words = c->words;
+    if (supports && c->H) HIPCHK(hipMemcpyAsync(supports, c->d_sup.p, sizeof(int32_t) * c->H, hipMemcpyDeviceToHost, c->stream));
+    if (masks && c->H && c->words) {
+        if (c->cfg.dedup) {
+            // expand per-position masks to per-hypothesis masks on the host
+            std::vector<uint64_t> pm((size_t)c->m * c->words);
+            std::vector<int32_t> pos((size_t)c->H);
+            HIPCHK(hipMemcpyAsync(pm.data(), c->d_posmask.p, sizeof(uint64_t) * pm.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(pos.data(), c->d_pos.p, sizeof(int32_t) * c->H, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < c->H; ++i)
+                memcpy(masks + (size_t)i * c->words, pm.data() + (size_t)pos[i] * c->words, sizeof(uint64_t) * c->words);
+        } else {
+            HIPCHK(hipMemcpyAsync(masks, c->d_masks.p, sizeof(uint64_t) * (size_t)c->H * c->words, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// kernel-level entry points
+// ------------------------------------------------------------------------
+extern "C" int rslam_k_rank_update(rslam_ctx* c, int32_t n, int32_t r, const double* dA, int32_t lda,
+                                   const double* dY, int32_t ldy, double* dC, int32_t ldc)
+{
+    if (!c || !dA || !dY || !dC || n <= 0 || r < 0) return RSLAM_ERR_ARG;
+    const int NP = round_up(n, 64), K = round_up(r, TG_KC_HOST);
+    if (lda < NP || ldc < NP || ldy < NP) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc);
+    HIPCHK(hipGetLastError());
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_k_gemm_nt(rslam_ctx* c, int32_t m, int32_t n, int32_t k, double alpha, const double* dA,
+                               int32_t lda, const double* dB, int32_t ldb, double beta, double* dC, int32_t ldc)
+{
+    if (!c || !dA || !dB || !dC) return RSLAM_ERR_ARG;
+    if (m <= 0 || n <= 0 || k <= 0 || (m % 64) || (n % 64) || (k % TG_KC_HOST)) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    launch_gemm_nt(c->stream, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc);
+    HIPCHK(hipGetLastError());
+    return RSLAM_OK;
+}
+
+// waves_per_simd = 1 or 2; cycles_per_mfma and clock_mhz (in-kernel, s_memtime / s_memrealtime) may be NULL
+extern "C" int rslam_k_mfma_f64_probe(rslam_ctx* c, int32_t waves_per_simd, double* tflops, double* cycles_per_mfma,
+                                      double* clock_mhz)
+{
+    if (!c || !tflops || waves_per_simd < 1 || waves_per_simd > 8) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount * waves_per_simd, iters = 20000;
+    if (c->d_probe.ensure((size_t)blocks * 256 + 8) < 0) return RSLAM_ERR_HIP;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(c->d_probe.p + (size_t)blocks * 256);
+    launch_mfma_probe(c->stream, blocks, 2000, c->d_probe.p, nullptr);       // warm-up
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, c->stream));
+    launch_mfma_probe(c->stream, blocks, iters, c->d_probe.p, stamps);
+    HIPCHK(hipEventRecord(b, c->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    unsigned long long st[2] = {0, 0};
+    HIPCHK(hipMemcpy(st, stamps, sizeof(st), hipMemcpyDeviceToHost));
+    const double flops = (double)blocks * 4.0 * (double)iters * 4.0 * 2048.0;   // 16x16x4 MFMA = 2048 flop
+    *tflops = flops / ((double)ms * 1e-3) * 1e-12;
+    // one SIMD executed waves_per_simd * 4 * iters MFMAs during st[0] shader cycles
+    if (cycles_per_mfma) *cycles_per_mfma = (double)st[0] / ((double)iters * 4.0 * waves_per_simd);
+    if (clock_mhz) *clock_mhz = st[1] ? (double)st[0] / (double)st[1] * 100.0 : 0.0;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_k_mfma_f64_peak(rslam_ctx* c, double* tflops)
+{
+    return rslam_k_mfma_f64_probe(c, 2, tflops, nullptr, nullptr);
+}
+
+extern "C" int rslam_k_hbm_copy_peak(rslam_ctx* c, int64_t bytes, double* gbps)
+{
+    if (!c || !gbps || bytes < 1024) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const long n = (long)(bytes / 16) * 2;
+    double *src = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc((void**)&src, n * sizeof(double)));
+    if (hipMalloc((void**)&dst, n * sizeof(double)) != hipSuccess) { (void)hipFree(src); return RSLAM_ERR_HIP; }
+    (void)hipMemsetAsync(src, 0, n * sizeof(double), c->stream);
+    launch_copy_probe(c->stream, src, dst, n);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, c->stream);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) launch_copy_probe(c->stream, src, dst, n);
+    (void)hipEventRecord(b, c->stream);
+    (void)hipEventSynchronize(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(src); (void)hipFree(dst);
+    *gbps = 2.0 * (double)n * 8.0 * reps / ((double)ms * 1e-3) * 1e-9;
+    return RSLAM_OK;
+}
