@@ -77,15 +77,17 @@ typedef struct rslam_layout {
 
 /* per-stage device times of the last frame, microseconds (hipEvent) */
 typedef struct rslam_stage_times {
-    double predict_us;     /* K1  h, Jacobians, S_i                         */
-    double pht_us;         /* K2  P*H^T for matched features                */
-    double score_us;       /* K3+K4 hypothesis scoring                      */
-    double select_us;      /* K5  consensus replay                          */
-    double update_li_us;   /* K6-K11 low-innovation update (all kernels)    */
-    double rescue_us;      /* K12 rescue gate                               */
-    double update_hi_us;   /* high-innovation update                        */
-    double rank_update_us; /* K10 alone (covariance rank-r update, LI pass) */
-    double factor_us;      /* K8 alone (blocked Cholesky + solves, LI pass) */
+    double predict_us;        /* K1  h, Jacobians, S_i                            */
+    double pht_us;            /* K2+K3 P*H^T for matched features, innovations     */
+    double score_us;          /* K4  hypothesis scoring                            */
+    double select_us;         /* K5  consensus replay + winner's inlier set        */
+    double update_li_us;      /* K6-K11 low-innovation update (all kernels)        */
+    double rescue_us;         /* K12 rescue gate                                   */
+    double update_hi_us;      /* high-innovation update (all kernels)              */
+    double factor_li_us;      /* K8 blocked Cholesky sweep, LI pass                */
+    double rank_update_li_us; /* K10 covariance rank-r update kernel, LI pass      */
+    double factor_hi_us;      /* K8, HI pass                                       */
+    double rank_update_hi_us; /* K10, HI pass                                      */
     double total_us;
 } rslam_stage_times;
 

@@ -48,6 +48,7 @@ def lib():
                                         _i32p, _i32p, _i32p]
         L.orc_ransac_only.argtypes = [C.c_void_p, _dp, _u8p, _dp, C.c_int32, C.c_int32, _u8p,
                                       _i32p, _i32p, _i32p]
+        L.orc_finish_update.argtypes = [C.c_void_p, _dp, _dp, _u8p, _u8p]
         L.orc_get_supports.argtypes = [C.c_void_p, _i32p, _i32p, _u64p, _i32p]
         L.orc_get_margins.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_get_H.argtypes = [C.c_void_p, _dp]
@@ -141,6 +142,16 @@ class Oracle:
         if rc:
             raise OracleError(rc)
         return dict(li=li, best_hyp=bh.value, best_support=bs.value, hyps_evaluated=he.value)
+
+    def finish_update(self):
+        x_new = np.zeros(self.n)
+        P_new = np.zeros((self.n, self.n), order="F")
+        li = np.zeros(self.L, np.uint8)
+        hi = np.zeros(self.L, np.uint8)
+        rc = lib().orc_finish_update(self._h, _p(x_new), _p(P_new), _p(li, _u8p), _p(hi, _u8p))
+        if rc:
+            raise OracleError(rc)
+        return dict(x_new=x_new, P_new=P_new, li=li, hi=hi)
 
     def supports(self):
         words = C.c_int32()

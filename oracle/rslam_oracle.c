@@ -954,6 +954,31 @@ int orc_ransac_only(orc_ctx* c, const double* z, const uint8_t* ic, const double
     return rc;
 }
 
+/* System::TrackRunning lines 123-129 from the flags left by orc_ransac_only
+ * (lets the CPU-baseline leg time the RANSAC sample and the updates separately). */
+int orc_finish_update(orc_ctx* c, double* x_new, double* P_new, uint8_t* li, uint8_t* hi)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->predicted) return RSLAM_ERR_STATE;
+    const int n = c->n;
+    int rc = ekf_update_flagged(c, c->li, c->x_k_km1, c->p_k_km1, c->x_k_k, c->p_k_k);
+    if (rc) return rc;
+    memcpy(c->x_li, c->x_k_k, sizeof(double) * n);
+    memcpy(c->p_li, c->p_k_k, sizeof(double) * (size_t)n * n);
+    rescue_hi_inliers(c);
+    double* x2 = (double*)malloc(sizeof(double) * n);
+    double* P2 = (double*)malloc(sizeof(double) * (size_t)n * n);
+    rc = ekf_update_flagged(c, c->hi, c->x_k_k, c->p_k_k, x2, P2);
+    memcpy(c->x_k_k, x2, sizeof(double) * n);
+    memcpy(c->p_k_k, P2, sizeof(double) * (size_t)n * n);
+    free(x2); free(P2);
+    if (x_new) memcpy(x_new, c->x_k_k, sizeof(double) * n);
+    if (P_new) memcpy(P_new, c->p_k_k, sizeof(double) * (size_t)n * n);
+    if (li) memcpy(li, c->li, (size_t)c->L);
+    if (hi) memcpy(hi, c->hi, (size_t)c->L);
+    return rc;
+}
+
 /* System::TrackRunning lines 120-129 */
 int orc_ransac_update(orc_ctx* c, const double* z, const uint8_t* ic, const double* draws,
                       int32_t n_draws, double* x_new, double* P_new, uint8_t* li, uint8_t* hi,

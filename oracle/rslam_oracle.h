@@ -55,6 +55,9 @@ int orc_ransac_only(orc_ctx* c, const double* z, const uint8_t* ic,
                     uint8_t* li, int32_t* best_hyp, int32_t* best_support,
                     int32_t* hyps_evaluated);
 
+/* Updates + rescue (System.cpp:123-129) from the flags orc_ransac_only left. */
+int orc_finish_update(orc_ctx* c, double* x_new, double* P_new, uint8_t* li, uint8_t* hi);
+
 /* Introspection for tests (valid after orc_ransac_update / orc_ransac_only). */
 int orc_get_supports(orc_ctx* c, int32_t* supports /* hyps_evaluated */,
                      int32_t* positions /* hyps_evaluated: hypothesised feature */,

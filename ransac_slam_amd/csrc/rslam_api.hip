@@ -46,7 +46,7 @@ struct DevBuf {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 enum { EV_START = 0, EV_PREDICT, EV_PHT, EV_SCORE, EV_SELECT, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0,
-       EV_LI_RANK1, EV_LI_END, EV_RESCUE, EV_HI_END, EV_COUNT };
+       EV_LI_RANK1, EV_LI_END, EV_RESCUE, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1, EV_HI_END, EV_COUNT };
 
 }  // namespace
 
@@ -414,7 +414,7 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
                    c->d_A.p + c->RP, c->ldA);
     rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
-                            c->d_P.p, c->d_P.p, -1, -1, -1, -1);
+                            c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);
     return RSLAM_OK;
@@ -442,8 +442,10 @@ static void collect_times(rslam_ctx* c)
     t.update_li_us = el(EV_SELECT, EV_LI_END);
     t.rescue_us = el(EV_LI_END, EV_RESCUE);
     t.update_hi_us = el(EV_RESCUE, EV_HI_END);
-    t.rank_update_us = el(EV_LI_RANK0, EV_LI_RANK1);
-    t.factor_us = el(EV_LI_FACTOR0, EV_LI_FACTOR1);
+    t.rank_update_li_us = el(EV_LI_RANK0, EV_LI_RANK1);
+    t.factor_li_us = el(EV_LI_FACTOR0, EV_LI_FACTOR1);
+    t.rank_update_hi_us = el(EV_HI_RANK0, EV_HI_RANK1);
+    t.factor_hi_us = el(EV_HI_FACTOR0, EV_HI_FACTOR1);
     t.total_us = el(EV_START, EV_HI_END);
 }
 

@@ -27,7 +27,8 @@ class Layout(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         "predict_us", "pht_us", "score_us", "select_us", "update_li_us",
-        "rescue_us", "update_hi_us", "rank_update_us", "factor_us", "total_us")]
+        "rescue_us", "update_hi_us", "factor_li_us", "rank_update_li_us",
+        "factor_hi_us", "rank_update_hi_us", "total_us")]
 
 
 RSLAM_OK = 0

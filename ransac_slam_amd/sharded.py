@@ -1,0 +1,85 @@
+"""Multi-GPU hypothesis sharding: one process per GPU, one exchange per frame.
+
+The hypothesis list 0..H-1 is cut into ``world`` contiguous slices.  Every rank
+holds the replicated frame (x, P, features, z), scores its slice (K2-K4), the
+int32 supports are all-gathered (RCCL over xGMI when the tensors live in HBM,
+gloo in the CPU tests), and every rank replays the sequential consensus scan
+(K5) on the full list -- bit-identical on all ranks, so the reference's "earliest
+strict maximum + adaptive stop" semantics (Tracking.cpp:403,507-537) survive the
+sharding -- and applies the updates redundantly (no 26 MB covariance broadcast).
+The only collective is that one all-gather of H * 4 bytes.
+"""
+from typing import Protocol, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def slice_bounds(H: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(begin, end, chunk) of the contiguous slice of rank; chunk = ceil(H / world)."""
+    chunk = (H + world - 1) // world
+    b = min(H, rank * chunk)
+    e = min(H, b + chunk)
+    return b, e, chunk
+
+
+class Engine(Protocol):
+    """What the driver needs from a per-rank engine (HIP product or a test double)."""
+    H: int
+    device: torch.device
+
+    def step_predict(self) -> None: ...
+    def step_score(self, hyp_begin: int, hyp_end: int, local: torch.Tensor) -> None:
+        """write supports of hypotheses [begin, end) into local[0 : end-begin] (int32)"""
+    def step_update(self, supports_all: torch.Tensor) -> None: ...
+
+
+class ShardedFrame:
+    def __init__(self, engine: Engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.resize()
+
+    def resize(self):
+        H = self.engine.H
+        self.begin, self.end, self.chunk = slice_bounds(H, self.rank, self.world)
+        dev = self.engine.device
+        self.local = torch.zeros(max(self.chunk, 1), dtype=torch.int32, device=dev)
+        self.all = torch.zeros(max(self.chunk, 1) * self.world, dtype=torch.int32, device=dev)
+
+    def step(self):
+        """One frame: predict, score own slice, exchange, consensus + updates."""
+        e = self.engine
+        e.step_predict()
+        e.step_score(self.begin, self.end, self.local)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.all, self.local, group=self.group)
+            e.step_update(self.all)
+        else:
+            e.step_update(self.local)
+
+
+class HipEngine:
+    """The product engine: ransac_slam_amd.api.RslamHip on this rank's GPU, enqueued
+    on torch's current stream so that the RCCL all-gather is ordered with the kernels."""
+
+    def __init__(self, ctx, device_index: int):
+        self.ctx = ctx
+        self.device = torch.device("cuda", device_index)
+        ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def H(self):
+        return self.ctx.H
+
+    def step_predict(self):
+        self.ctx.step_predict()
+
+    def step_score(self, hyp_begin, hyp_end, local):
+        # the C ABI indexes the support array by global hypothesis id
+        self.ctx.step_score(hyp_begin, hyp_end, local.data_ptr() - 4 * hyp_begin)
+
+    def step_update(self, supports_all):
+        self.ctx.step_update(supports_all.data_ptr())

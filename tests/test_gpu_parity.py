@@ -1,0 +1,362 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle,
+the committed golden vectors and size-independent properties.  Need an MI355X.
+
+Tolerances (BASELINE.json north_star): inlier index sets, supports, masks and the
+consensus scalars bit-exact; state and covariance within 1e-5 relative -- the tests
+assert 1e-9 of the largest entry, four orders tighter.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from ransac_slam_amd import default_config
+from ransac_slam_amd.synth import make_frame
+
+pytestmark = pytest.mark.gpu
+
+X_TOL = 1e-9     # |dx| <= X_TOL * max(1, max|x|)
+P_TOL = 1e-9     # |dP| <= P_TOL * max|P|
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (the product path has no CPU fallback)")
+    from ransac_slam_amd import api
+    api.lib()          # raises loudly if librslam_hip.so is missing
+    return api
+
+
+def close_x(a, b):
+    return np.max(np.abs(a - b)) <= X_TOL * max(1.0, float(np.max(np.abs(b))))
+
+
+def close_P(a, b):
+    return np.max(np.abs(a - b)) <= P_TOL * float(np.max(np.abs(b)))
+
+
+def run_both(hip, oracle_lib, fr, cfg, structure=0):
+    o = oracle_lib.Oracle(cfg, structure=structure)
+    h0, v0, S0 = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    g = hip.RslamHip(cfg)
+    h1, v1, S1 = g.predict(fr.types, fr.x_pred, fr.P_pred)
+    assert np.array_equal(v0, v1)
+    vis = v0.astype(bool)
+    assert np.allclose(h1[vis], h0[vis], rtol=0, atol=1e-9)
+    assert np.allclose(S1[vis], S0[vis], rtol=1e-10, atol=1e-12)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z, ic, fr.draws)
+    r1 = g.ransac_update(fr.z, ic, fr.draws)
+    return o, g, r0, r1
+
+
+def check_frame(o, g, r0, r1):
+    sup0, pos0, masks0 = o.supports()
+    sup1, masks1 = g.fetch_supports()
+    ne = len(sup0)
+    assert np.array_equal(sup1[:ne], sup0)
+    assert np.array_equal(masks1[:ne], masks0)
+    for k in ("best_hyp", "best_support", "hyps_evaluated"):
+        assert r1[k] == r0[k], k
+    assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+    assert close_x(r1["x_new"], r0["x_new"])
+    assert close_P(r1["P_new"], r0["P_new"])
+    sm, rm = o.margins()
+    assert sm > 1e-9 and rm > 1e-9        # margin audit: the integer outputs are well defined
+
+
+# --------------------------------------------------------------------------- kernels
+def test_mfma_gemm_nt_matches_torch(hip):
+    import torch
+    ctx = hip.RslamHip(default_config())
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1)
+    for (M, N, K) in [(64, 64, 32), (64, 128, 96), (192, 128, 512), (320, 64, 64)]:
+        A = torch.randn(K, M, dtype=torch.float64, device=dev, generator=g)    # col-major M x K
+        B = torch.randn(K, N, dtype=torch.float64, device=dev, generator=g)    # col-major N x K, asymmetric
+        C0 = torch.randn(N, M, dtype=torch.float64, device=dev, generator=g)
+        Cm = C0.clone()
+        torch.cuda.synchronize()
+        ctx.k_gemm_nt(M, N, K, 1.5, A.data_ptr(), M, B.data_ptr(), N, -0.5, Cm.data_ptr(), M)
+        ctx.sync()
+        ref = 1.5 * (B.T @ A) - 0.5 * C0      # [j, i] = C(i, j)
+        assert float((Cm - ref).abs().max()) <= 1e-12 * K
+    ctx.close()
+
+
+def test_rank_update_kernel_matches_torch(hip):
+    import torch
+    ctx = hip.RslamHip(default_config())
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2)
+    for (n, r) in [(64, 32), (200, 70), (333, 5), (130, 0)]:
+        NP, KP = -(-n // 64) * 64, max(32, -(-r // 32) * 32)
+        P = torch.randn(NP, NP, dtype=torch.float64, device=dev, generator=g)   # deliberately not symmetric
+        P[n:, :] = 0; P[:, n:] = 0
+        Y = torch.zeros(KP, NP, dtype=torch.float64, device=dev)
+        if r:
+            Y[:r, :n] = torch.randn(r, n, dtype=torch.float64, device=dev, generator=g)
+        C = torch.full((NP, NP), 7.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ctx.k_rank_update(n, r, P.data_ptr(), NP, Y.data_ptr(), NP, C.data_ptr(), NP)
+        ctx.sync()
+        ref = (0.5 * (P + P.T) - Y.T @ Y) if r else P      # r == 0: exact pass-through (ExtendKF.cpp:635-638)
+        assert float((C - ref).abs().max()) <= 1e-12 * max(r, 1)
+        if r:
+            assert float((C - C.T).abs().max()) == 0.0        # bitwise symmetric
+        Pi = P.clone()
+        ctx.k_rank_update(n, r, Pi.data_ptr(), NP, Y.data_ptr(), NP, Pi.data_ptr(), NP)   # in place
+        ctx.sync()
+        assert float((Pi - ref).abs().max()) <= 1e-12 * max(r, 1)
+    ctx.close()
+
+
+# --------------------------------------------------------------------------- goldens
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_matches_golden(hip, path):
+    gld = np.load(path)
+    for compat, adaptive in [(1, 1), (0, 1), (0, 0)]:
+        tag = f"c{compat}a{adaptive}"
+        cfg = default_config(compat=compat, adaptive=adaptive)
+        g = hip.RslamHip(cfg)
+        h, vis, S = g.predict(gld["types"], gld["x_pred"], gld["P_pred"])
+        assert np.array_equal(vis, gld["visible"])
+        v = vis.astype(bool)
+        assert np.allclose(h[v], gld["h"][v], rtol=0, atol=1e-9)
+        assert np.allclose(S[v], gld["S"][v], rtol=1e-10)
+        err = int(gld[f"{tag}_error"])
+        if err:
+            with pytest.raises(hip.RslamError) as e:
+                g.ransac_update(gld["z"], gld["ic"], gld["draws"])
+            assert e.value.code == err
+            g.close()
+            continue
+        r = g.ransac_update(gld["z"], gld["ic"], gld["draws"])
+        sup, masks = g.fetch_supports()
+        ne = len(gld[f"{tag}_supports"])
+        assert np.array_equal(sup[:ne], gld[f"{tag}_supports"])
+        assert np.array_equal(masks[:ne], gld[f"{tag}_masks"])
+        assert [r["best_hyp"], r["best_support"], r["hyps_evaluated"]] == list(gld[f"{tag}_scalars"])
+        assert np.array_equal(r["li"], gld[f"{tag}_li"]) and np.array_equal(r["hi"], gld[f"{tag}_hi"])
+        assert close_x(r["x_new"], gld[f"{tag}_x_new"])
+        if f"{tag}_P_new" in gld:
+            assert close_P(r["P_new"], gld[f"{tag}_P_new"])
+        g.close()
+
+
+# --------------------------------------------------------------------------- oracle, seeded frames
+CASES = [
+    dict(L=1, H=8, seed=201),                                   # single landmark
+    dict(L=7, H=16, seed=202),                                  # n = 55: far below one 64-tile
+    dict(L=33, H=64, seed=203, frac_ic=0.6),                    # ragged IC set, 2m not a multiple of 64
+    dict(L=70, H=128, seed=204),                                # m > 64: two mask words
+    dict(L=48, H=100, seed=205, frac_cartesian=0.5),            # mixed feature types (fixed mode only)
+    dict(L=64, H=100, seed=206, frac_outlier=0.0),              # every match an inlier
+    dict(L=40, H=60, seed=207, frac_outlier=1.0),               # every match an outlier
+    dict(L=120, H=300, seed=208, frac_ic=0.9),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "L%d_H%d_s%d" % (c["L"], c["H"], c["seed"]))
+@pytest.mark.parametrize("mode", [(1, 1), (0, 1), (0, 0), (1, 0)], ids=lambda m: "compat%d_adaptive%d" % m)
+def test_frame_matches_oracle(hip, oracle_lib, case, mode):
+    compat, adaptive = mode
+    fr = make_frame(**case)
+    if compat and 0 < (fr.types == 1).sum():
+        pytest.skip("compat mode with Cartesian features is the reference's assertion case (tested separately)")
+    o, g, r0, r1 = run_both(hip, oracle_lib, fr, default_config(compat=compat, adaptive=adaptive))
+    check_frame(o, g, r0, r1)
+    g.close()
+
+
+def test_dedup_and_graph_and_resident_api_agree(hip, oracle_lib):
+    fr = make_frame(L=90, H=400, seed=301)
+    for compat in (1, 0):
+        cfg0 = default_config(compat=compat, adaptive=1, dedup=0)
+        o, g, r0, r1 = run_both(hip, oracle_lib, fr, cfg0, structure=1)
+        check_frame(o, g, r0, r1)
+        ic = (fr.ic & g.fetch_prediction()[1]).astype(np.uint8)
+        g.close()
+        for dedup in (0, 1):
+            for use_graph in (False, True):
+                c = hip.RslamHip(default_config(compat=compat, adaptive=1, dedup=dedup))
+                c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+                for _ in range(3):                      # replays start from the same resident prior
+                    c.step_frame(use_graph)
+                c.sync()
+                r = c.fetch_results()
+                sup, masks = c.fetch_supports()
+                sup0, _, masks0 = o.supports()
+                assert np.array_equal(sup[:len(sup0)], sup0) and np.array_equal(masks[:len(sup0)], masks0)
+                for k in ("best_hyp", "best_support", "hyps_evaluated"):
+                    assert r[k] == r0[k]
+                assert np.array_equal(r["li"], r0["li"]) and np.array_equal(r["hi"], r0["hi"])
+                assert r["n_li"] == int(r0["li"].sum()) and r["n_hi"] == int(r0["hi"].sum())
+                assert close_x(r["x_new"], r0["x_new"]) and close_P(r["P_new"], r0["P_new"])
+                c.close()
+
+
+def test_sharded_scoring_equals_full(hip):
+    """Two hypothesis slices scored separately (what two ranks do) == one full pass."""
+    import torch
+    fr = make_frame(L=60, H=257, seed=302)
+    cfg = default_config(compat=0, adaptive=1)
+    c = hip.RslamHip(cfg)
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    c.step_frame(False); c.sync()
+    full = c.fetch_results()
+    sup_full, _ = c.fetch_supports()
+    sup = torch.zeros(257, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    c.step_predict()
+    c.step_score(129, 257, sup.data_ptr())
+    c.step_score(0, 129, sup.data_ptr())
+    c.step_update(sup.data_ptr())
+    c.sync()
+    part = c.fetch_results()
+    assert np.array_equal(sup.cpu().numpy(), sup_full)
+    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+        assert part[k] == full[k]
+    assert np.array_equal(part["li"], full["li"]) and np.array_equal(part["hi"], full["hi"])
+    assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+    c.close()
+
+
+# --------------------------------------------------------------------------- edge cases / errors
+def test_no_matches_is_pass_through(hip, oracle_lib):
+    fr = make_frame(L=12, H=10, seed=401)
+    fr.ic[:] = 0
+    for compat in (1, 0):
+        o, g, r0, r1 = run_both(hip, oracle_lib, fr, default_config(compat=compat))
+        assert r1["best_hyp"] == -1 and r1["li"].sum() == 0 and r1["hi"].sum() == 0
+        assert np.array_equal(r1["x_new"], fr.x_pred)              # ExtendKF.cpp:635-638: untouched
+        assert np.array_equal(r1["P_new"], np.asarray(fr.P_pred))
+        assert np.array_equal(r0["P_new"], np.asarray(fr.P_pred))
+        g.close()
+
+
+def test_empty_map(hip):
+    g = hip.RslamHip(default_config())
+    x = np.zeros(13); x[3] = 1.0
+    P = np.eye(13) * 1e-3
+    h, vis, S = g.predict(np.zeros(0, np.uint8), x, P)
+    assert h.shape == (0, 2)
+    r = g.ransac_update(np.zeros((0, 2)), np.zeros(0, np.uint8), np.array([0.5, 0.25]))
+    assert np.array_equal(r["x_new"], x) and np.array_equal(r["P_new"], P)
+    g.close()
+
+
+def test_invisible_features_and_ic_check(hip, oracle_lib):
+    fr = make_frame(L=10, H=8, seed=402)
+    fr.x_pred[fr.offsets[3] + 3] += 2.5           # swing one landmark's azimuth out of the +-60 degree FOV
+    fr.x_pred[fr.offsets[6] + 4] += 1.2           # and one out of the image
+    o = oracle_lib.Oracle(default_config())
+    h0, v0, S0 = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    g = hip.RslamHip(default_config())
+    h1, v1, S1 = g.predict(fr.types, fr.x_pred, fr.P_pred)
+    assert np.array_equal(v0, v1) and v0.sum() < 10
+    assert np.isnan(h1[~v1.astype(bool)]).all()    # untouched for invisible features
+    bad_ic = np.ones(10, np.uint8)
+    with pytest.raises(hip.RslamError) as e:
+        g.ransac_update(fr.z, bad_ic, fr.draws)
+    assert e.value.code == -7
+    r1 = g.ransac_update(fr.z, v1, fr.draws)
+    r0 = o.ransac_update(fr.z, v0, fr.draws)
+    assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+    assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+    g.close()
+
+
+def test_compat_cartesian_mismatch_returns_ref_assert(hip):
+    fr = make_frame(L=9, H=4, seed=71, frac_cartesian=0.3)
+    g = hip.RslamHip(default_config(compat=1))
+    _, vis, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+    with pytest.raises(hip.RslamError) as e:
+        g.ransac_update(fr.z, fr.ic & vis, fr.draws)
+    assert e.value.code == -5                      # the reference Eigen-asserts here (Tracking.cpp:498)
+    g.close()
+
+
+def test_call_order_and_argument_errors(hip):
+    g = hip.RslamHip(default_config())
+    with pytest.raises(hip.RslamError) as e:
+        g.n, g.L = 13, 0
+        g.ransac_update(np.zeros((0, 2)), np.zeros(0, np.uint8), np.array([0.1]))
+    assert e.value.code == -4                      # update before predict
+    with pytest.raises(hip.RslamError) as e:
+        g.step_frame(False)
+    assert e.value.code == -4
+    g.close()
+
+
+# --------------------------------------------------------------------------- full size
+def _properties(fr, ic, r):
+    n = fr.n
+    P0, P1 = np.asarray(fr.P_pred), r["P_new"]
+    assert np.array_equal(P1, P1.T)                                    # exactly symmetric
+    assert abs(np.linalg.norm(r["x_new"][3:7]) - 1.0) < 1e-12 or (r["n_li"] + r["n_hi"] == 0)
+    li, hi = r["li"].astype(bool), r["hi"].astype(bool)
+    assert not (li & hi).any() and not (li & ~ic.astype(bool)).any() and not (hi & ~ic.astype(bool)).any()
+    # information never decreases: v^T (P0 - P1) v >= 0 away from the renormalised quaternion rows
+    rng = np.random.default_rng(0)
+    keep = np.r_[0:3, 7:n]
+    D = (P0 - P1)[np.ix_(keep, keep)]
+    for _ in range(8):
+        v = rng.normal(size=len(keep))
+        assert v @ D @ v >= -1e-9 * np.abs(D).max() * len(keep)
+
+
+@pytest.mark.parametrize("compat", [1, 0])
+def test_c3_full_size_against_structured_oracle(hip, oracle_lib, compat):
+    """BASELINE config C3 (300 landmarks, 1000 hypotheses): oracle in structured mode."""
+    fr = make_frame(L=300, H=1000, seed=2)
+    cfg = default_config(compat=compat, adaptive=1)
+    o, g, r0, r1 = run_both(hip, oracle_lib, fr, cfg, structure=1)
+    check_frame(o, g, r0, r1)
+    ic = fr.ic & g.fetch_prediction()[1]
+    r1.update(n_li=int(r1["li"].sum()), n_hi=int(r1["hi"].sum()))
+    _properties(fr, ic, r1)
+    # all 1000 hypotheses (adaptive off): supports and masks bit-exact
+    cfg = default_config(compat=compat, adaptive=0)
+    o = oracle_lib.Oracle(cfg, structure=1)
+    o.predict(fr.types, fr.x_pred, fr.P_pred)
+    o.ransac_only(fr.z, ic, fr.draws)
+    sup0, _, masks0 = o.supports()
+    g2 = hip.RslamHip(cfg)
+    g2.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+    g2.step_frame(False); g2.sync()
+    sup1, masks1 = g2.fetch_supports()
+    assert np.array_equal(sup1, sup0) and np.array_equal(masks1, masks0)
+    assert o.margins()[0] > 1e-9
+    g.close(); g2.close()
+
+
+def test_c5_size_properties(hip):
+    """1000 landmarks (n = 6013): too large for the oracle in test time; size-independent
+    properties + agreement of the dedup and graph paths."""
+    fr = make_frame(L=1000, H=1000, seed=4)
+    outs = []
+    for dedup, use_graph in ((0, False), (1, True)):
+        c = hip.RslamHip(default_config(compat=0, adaptive=0, dedup=dedup))
+        c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+        c.step_predict(); c.sync()
+        vis = c.fetch_prediction()[1]
+        ic = fr.ic & vis
+        c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+        c.step_frame(use_graph); c.sync()
+        r = c.fetch_results()
+        outs.append(r)
+        c.close()
+    _properties(fr, ic, outs[0])
+    assert outs[0]["best_support"] > 100 and outs[0]["n_li"] == outs[0]["best_support"]
+    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+        assert outs[0][k] == outs[1][k]
+    assert np.array_equal(outs[0]["li"], outs[1]["li"]) and np.array_equal(outs[0]["hi"], outs[1]["hi"])
+    assert close_x(outs[1]["x_new"], outs[0]["x_new"]) and close_P(outs[1]["P_new"], outs[0]["P_new"])
+    # truth consistency: the filter moved towards the truth it was sampled around
+    e0 = np.linalg.norm((fr.x_pred - fr.x_true)[:3]); e1 = np.linalg.norm((outs[0]["x_new"] - fr.x_true)[:3])
+    assert e1 < e0
