@@ -126,6 +126,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(2):                             # let the sweep launch sizing settle (needs a sync)
+        step()
+        ctx.sync()
     for _ in range(args.warmup):
         step()
     fence()

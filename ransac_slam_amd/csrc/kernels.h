@@ -13,6 +13,9 @@ enum SelSlot {
     SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7,
     SEL_COUNT = 16
 };
+// internal device status: the captured launch sequence of a factor sweep was shorter than the
+// inlier count needs (the host re-runs the update stage with the full-length sequence)
+constexpr int STATUS_SWEEP_CAP = -100;
 
 constexpr int TG_KC_HOST = 32;   // K granularity of the MFMA tile engine (tile_gemm.h TG_KC)
 
@@ -51,11 +54,11 @@ void launch_select(hipStream_t s, const int32_t* sup, int H, const int32_t* nhyp
 // re-score the winning hypothesis and scatter its mask to li[], build list/count
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
-                      const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
+                      const int32_t* pos, double threshold, int L, int cap_blocks, int32_t* sel, uint8_t* li,
                       int32_t* list);
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
-                        const double* S, const double* z, const double* h, double chi2,
+                        const double* S, const double* z, const double* h, double chi2, int cap_blocks,
                         uint8_t* hi, int32_t* list, int32_t* sel);
 
 struct SystemDims { int n, NP, RP, ldA; };   // stacked matrix A: rows [0,RP) S | [RP,RP+NP) W | RP+NP: nu^T (+63 pad)
@@ -65,7 +68,7 @@ void launch_gather_w(hipStream_t s, const SystemDims& d, const double* W, const 
 void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* list, const int32_t* sel,
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
                            const uint8_t* type, const double* z, const double* h, double* A);
-void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk,
+void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk, int cap_blocks,
                          double* A, double* Linv, int32_t* status_sel);
 void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
                          const double* A, const double* x_in, double* x_out, double* T, int compat);

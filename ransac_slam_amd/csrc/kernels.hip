@@ -23,41 +23,60 @@ namespace rslam {
 // Tracking::calculate_derivatives (Tracking.cpp:540-573) and the S_i loop of
 // Tracking::search_IC_matches (Tracking.cpp:39-44) / rescue (:589).
 // ---------------------------------------------------------------------------
+// 16 lanes per feature: the scalar camera/Jacobian arithmetic is done redundantly by the
+// group (latency-bound either way), the 13 x 13 gather of P for S_i is split one column
+// per lane and reduced with shuffles.
 __global__ void __launch_bounds__(64)
 predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ P, int NP, int L,
                const uint8_t* __restrict__ type, const int32_t* __restrict__ off,
                double* h, uint8_t* has_h, uint8_t* vis, double* __restrict__ H13, double* __restrict__ S,
                double radd)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    if (i >= L) return;                       // whole 16-lane group leaves together
     const bool is_id = (type[i] == 0);
     const int o = off[i];
     double u, v;
     const bool visible = predict_feature(cam, x, o, is_id, u, v);
-    bool have = has_h[i] != 0;
-    if (visible) { h[2 * i] = u; h[2 * i + 1] = v; has_h[i] = 1; have = true; }
-    if (vis) vis[i] = visible ? 1 : 0;
+    const bool have = visible || (has_h[i] != 0);
+    double hu_ = u, hv_ = v;
+    if (!visible && have) { hu_ = h[2 * i]; hv_ = h[2 * i + 1]; }     // stale h (ExtendKF.cpp:77-78)
+    if (sub == 0) {
+        if (visible) { h[2 * i] = u; h[2 * i + 1] = v; has_h[i] = 1; }
+        if (vis) vis[i] = visible ? 1 : 0;
+    }
     if (!have) return;
-    const double hu_ = visible ? u : h[2 * i], hv_ = visible ? v : h[2 * i + 1];
     double Hc[26];
     feature_jacobian(cam, x, o, is_id, hu_, hv_, Hc);
+    if (sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 26; ++k) H13[26 * i + k] = Hc[k];
-    const int w = is_id ? 13 : 10;
-    double s00 = 0, s10 = 0, s01 = 0, s11 = 0;
-    for (int jj = 0; jj < w; ++jj) {
-        const long cj = col_index(o, jj);
-        double t0 = 0, t1 = 0;
-        for (int kk = 0; kk < w; ++kk) {
-            const double p = P[col_index(o, kk) + cj * NP];
-            t0 += Hc[kk] * p;
-            t1 += Hc[13 + kk] * p;
-        }
-        s00 += t0 * Hc[jj];       s10 += t1 * Hc[jj];
-        s01 += t0 * Hc[13 + jj];  s11 += t1 * Hc[13 + jj];
+        for (int k = 0; k < 26; ++k) H13[26 * i + k] = Hc[k];
     }
-    S[4 * i + 0] = s00 + radd; S[4 * i + 1] = s10; S[4 * i + 2] = s01; S[4 * i + 3] = s11 + radd;
+    const int w = is_id ? 13 : 10;
+    // lane `sub` owns column jj = sub of (H P)
+    double t0 = 0, t1 = 0, hj0 = 0, hj1 = 0;
+    if (sub < w) {
+        const long cj = col_index(o, sub);
+#pragma unroll
+        for (int kk = 0; kk < 13; ++kk) {
+            if (kk < w) {
+                const double p = P[col_index(o, kk) + cj * NP];
+                t0 += Hc[kk] * p;
+                t1 += Hc[13 + kk] * p;
+            }
+            if (kk == sub) { hj0 = Hc[kk]; hj1 = Hc[13 + kk]; }
+        }
+    }
+    double s00 = t0 * hj0, s10 = t1 * hj0, s01 = t0 * hj1, s11 = t1 * hj1;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        s00 += __shfl_xor(s00, d, 16); s10 += __shfl_xor(s10, d, 16);
+        s01 += __shfl_xor(s01, d, 16); s11 += __shfl_xor(s11, d, 16);
+    }
+    if (sub == 0) {
+        S[4 * i + 0] = s00 + radd; S[4 * i + 1] = s10; S[4 * i + 2] = s01; S[4 * i + 3] = s11 + radd;
+    }
 }
 
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
@@ -65,7 +84,7 @@ void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double
                     uint8_t* vis, double* H13, double* S, double radd)
 {
     if (L <= 0) return;
-    predict_kernel<<<dim3((L + 63) / 64), dim3(64), 0, s>>>(cam, x, P, NP, L, type, off, h, has_h, vis, H13, S, radd);
+    predict_kernel<<<dim3((L + 3) / 4), dim3(64), 0, s>>>(cam, x, P, NP, L, type, off, h, has_h, vis, H13, S, radd);
 }
 
 // ---------------------------------------------------------------------------
@@ -360,7 +379,7 @@ __device__ __forceinline__ int block_compact(bool flag, int* s_wave, int* runnin
 __global__ void __launch_bounds__(1024)
 best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
                  const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
-                 const int32_t* __restrict__ pos, double thr, int L, int32_t* __restrict__ sel,
+                 const int32_t* __restrict__ pos, double thr, int L, int cap_blocks, int32_t* __restrict__ sel,
                  uint8_t* __restrict__ li, int32_t* __restrict__ list)
 {
     __shared__ int s_wave[16];
@@ -381,16 +400,19 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int nblk = (2 * s_running + 63) / 64;
         sel[SEL_K_LI] = s_running;
-        sel[SEL_NBLK_LI] = (2 * s_running + 63) / 64;
+        sel[SEL_NBLK_LI] = nblk;
+        if (nblk > cap_blocks) atomicMin(sel + SEL_STATUS, STATUS_SWEEP_CAP);   // launch sequence too short: re-run
     }
 }
 
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
-                      const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li, int32_t* list)
+                      const int32_t* pos, double threshold, int L, int cap_blocks, int32_t* sel, uint8_t* li,
+                      int32_t* list)
 {
-    best_mask_kernel<<<dim3(1), dim3(score_block_size(m)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, sel, li, list);
+    best_mask_kernel<<<dim3(1), dim3(score_block_size(m)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, cap_blocks, sel, li, list);
 }
 
 // ---------------------------------------------------------------------------
@@ -400,7 +422,7 @@ void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const doub
 __global__ void __launch_bounds__(1024)
 rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restrict__ li,
                    const uint8_t* __restrict__ has_h, const double* __restrict__ S,
-                   const double* __restrict__ z, const double* __restrict__ h, double chi2,
+                   const double* __restrict__ z, const double* __restrict__ h, double chi2, int cap_blocks,
                    uint8_t* __restrict__ hi, int32_t* __restrict__ list, int32_t* __restrict__ sel)
 {
     __shared__ int s_wave[16];
@@ -424,19 +446,21 @@ rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restr
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int nblk = (2 * s_running + 63) / 64;
         sel[SEL_K_HI] = s_running;
-        sel[SEL_NBLK_HI] = (2 * s_running + 63) / 64;
+        sel[SEL_NBLK_HI] = nblk;
+        if (nblk > cap_blocks) atomicMin(sel + SEL_STATUS, STATUS_SWEEP_CAP);
     }
 }
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
-                        const double* S, const double* z, const double* h, double chi2,
+                        const double* S, const double* z, const double* h, double chi2, int cap_blocks,
                         uint8_t* hi, int32_t* list, int32_t* sel)
 {
     int bs = ((L + 63) / 64) * 64;
     if (bs < 64) bs = 64;
     if (bs > 1024) bs = 1024;
-    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, hi, list, sel);
+    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, cap_blocks, hi, list, sel);
 }
 
 // ---------------------------------------------------------------------------
@@ -517,49 +541,188 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
 // row RP+NP holds u^T = nu^T L^-T, so that K S K^T = Y Y^T and K nu = Y u
 // (ExtendKF.cpp:603,606,608 use an explicit PartialPivLU inverse of S instead).
 // ---------------------------------------------------------------------------
+// Diagonal-block factorisation: one workgroup factors the 64 x 64 block in
+// registers.  Thread (i = t & 63, g = t >> 6) owns row i, columns 16g..16g+15 of
+// ONE array that holds A(i,c) until column c has been eliminated and (L^-1)(i,c)
+// afterwards (the row operations that build L are applied to the identity at the
+// same time, so L^-1 is ready when the last pivot is done and the panel solve
+// becomes an MFMA product).  Per pivot the only shared data is one 64-entry
+// vector X (column j of the trailing matrix below the diagonal, row j of the
+// partial inverse left of it), double-buffered in LDS: one barrier per pivot.
+__device__ __forceinline__ double rsqrt_f64(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);              // ~2^-26 relative
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);                       // two Newton steps -> full double
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
+// ---- 64 x 64 diagonal block: 16 x 16 sub-blocked Cholesky + inverse -------------
+// The block lives in LDS (column-major, ld 65).  Only the four 16 x 16 diagonal
+// sub-blocks go through scalar pivot steps (one wave, register resident, LDS
+// broadcast vector, no workgroup barrier inside); every other sub-block operation
+// -- sub-panel solve X * Li^T, trailing update, and the off-diagonal blocks of
+// L^-1 -- is a 16x16x16 product on v_mfma_f64_16x16x4_f64.
 constexpr int CD_LD = 65;
+
+// wave-level 16 x 16 Cholesky + inverse of the sub-block at (o,o) of T.
+// Lane i (< 16) owns row i: 16 registers that hold A(i,c) until column c is eliminated and
+// (L^-1)(i,c) afterwards.  Everything a pivot step shares -- the pivot, L(c,j) of the rows
+// below, row j of the partial inverse -- is a (static lane, static register) pair, so it is
+// broadcast with v_readlane through SGPRs: no LDS round trip on the 16-pivot chain.
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ bool factor16(double* T, double* M, int o)
+{
+    const int i = threadIdx.x & 63;          // rows 16..63 compute along harmlessly and store nothing
+    const int ir = i & 15;
+    double val[16], lcol[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        val[c] = (ir >= c) ? T[(o + c) * CD_LD + o + ir] : T[(o + ir) * CD_LD + o + c];
+        lcol[c] = 0.0;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double dj = readlane_f64(val[j], j);
+        bad = bad || !(dj > 0.0);
+        const double rinv = rsqrt_f64(dj);
+        const double lij = val[j] * rinv;            // L(i,j) for i >= j
+        const double nl = -lij;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c > j) {                             // Schur update of A(i,c): needs L(c,j) = A(c,j) * rinv
+                const double lcj = readlane_f64(val[j], c) * rinv;
+                const double upd = fma(nl, lcj, val[c]);
+                val[c] = (ir >= c) ? upd : val[c];
+            } else if (c < j) {                      // row operation on L^-1: needs (L^-1)(j,c) after scaling
+                const double mjc = readlane_f64(val[c], j) * rinv;
+                const double upd = fma(nl, mjc, val[c]);
+                val[c] = (ir > j) ? upd : ((ir == j) ? mjc : val[c]);
+            }
+        }
+        lcol[j] = lij;
+        val[j] = (ir == j) ? rinv : ((ir > j) ? nl * rinv : 0.0);
+    }
+    if (i < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            M[(o + c) * CD_LD + o + i] = (i >= c) ? val[c] : 0.0;      // L^-1 block, upper part zero
+            T[(o + c) * CD_LD + o + i] = (i >= c) ? lcol[c] : 0.0;     // L block, upper part zero
+        }
+    }
+    return bad;
+}
+
+// 16x16x16 products on sub-blocks of LDS matrices (ld CD_LD, column-major)
+__device__ __forceinline__ d4 mm16_nt(const double* P, int pr, int pc, const double* Q, int qr, int qc, d4 acc)
+{   // acc += P[pr.., pc..] * Q[qr.., qc..]^T
+    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+        const double a = P[(pc + kk + kq) * CD_LD + pr + i];
+        const double b = Q[(qc + kk + kq) * CD_LD + qr + i];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ d4 mm16_nn(const double* P, int pr, int pc, const double* Q, int qr, int qc, d4 acc)
+{   // acc += P[pr.., pc..] * Q[qr.., qc..]
+    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+        const double a = P[(pc + kk + kq) * CD_LD + pr + i];
+        const double b = Q[(qc + i) * CD_LD + qr + kk + kq];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// C[cr.., cc..] = alpha * acc + beta * C   (lane l holds rows (l>>4)+4*reg, column l&15)
+__device__ __forceinline__ void st16(double* C, int cr, int cc, d4 acc, double alpha, double beta)
+{
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        double* p = C + (cc + (l & 15)) * CD_LD + cr + (l >> 4) + 4 * reg;
+        *p = (beta != 0.0) ? alpha * acc[reg] + beta * (*p) : alpha * acc[reg];
+    }
+}
 
 __global__ void __launch_bounds__(256)
 chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
                  double* __restrict__ Linv, int32_t* __restrict__ status)
 {
     if (step >= sel[slot_nblk]) return;
-    __shared__ double T[64 * CD_LD];
-    __shared__ double M[64 * CD_LD];
+    __shared__ double T[64 * CD_LD];        // A block -> L
+    __shared__ double M[64 * CD_LD];        // L^-1
+    __shared__ double G[4][16 * CD_LD];     // per-wave 16 x 16 scratch
     const int t = threadIdx.x;
-    const int i = t & 63, g = t >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
-    for (int q = 0; q < 16; ++q) {
-        const int c = g + 4 * q;
-        // lower triangle is authoritative; mirror it
-        const double v = (i >= c) ? tile[i + (long)c * ldA] : tile[c + (long)i * ldA];
-        T[i * CD_LD + c] = v;
-        M[i * CD_LD + c] = (i == c) ? 1.0 : 0.0;
-    }
     double* Lout = Linv + (long)step * 64 * 64;
+    {
+        const int i = t & 63, g = t >> 6;
+        for (int q = 0; q < 16; ++q) {
+            const int c = g + 4 * q;     // the lower triangle is authoritative; mirror it
+            T[c * CD_LD + i] = (i >= c) ? tile[i + (long)c * ldA] : tile[c + (long)i * ldA];
+            M[c * CD_LD + i] = 0.0;
+        }
+    }
+    __syncthreads();
     bool bad = false;
-    for (int j = 0; j < 64; ++j) {
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    for (int sb = 0; sb < 4; ++sb) {
+        const int o = 16 * sb;
+        if (wave == 0) bad = factor16(T, M, o) || bad;
         __syncthreads();
-        const double dj = T[j * CD_LD + j];
-        if (!(dj > 0.0)) bad = true;
-        const double rinv = 1.0 / sqrt(dj);
-        const double lij = T[i * CD_LD + j] * rinv;
+        // sub-panel: T[a][sb] <- T[a][sb] * Li_sb^T for the sub-blocks below
+        const int a = sb + 1 + wave;
+        if (a < 4) {
+            const d4 acc = mm16_nt(T, 16 * a, o, M, o, o, zero);
+            st16(T, 16 * a, o, acc, 1.0, 0.0);       // the wave has read the whole block before it writes
+        }
+        __syncthreads();
+        // trailing: T[a][b] -= L[a][sb] * L[b][sb]^T for sb < b <= a
+        int idx = 0;
+        for (int ta = sb + 1; ta < 4; ++ta)
+            for (int tb = sb + 1; tb <= ta; ++tb, ++idx)
+                if ((idx & 3) == wave) {
+                    const d4 acc = mm16_nt(T, 16 * ta, o, T, 16 * tb, o, zero);
+                    st16(T, 16 * ta, 16 * tb, acc, -1.0, 1.0);
+                }
+        __syncthreads();
+    }
+    // off-diagonal blocks of L^-1 by block distance d: Linv[a][b] = -Li_aa * sum_{t=b}^{a-1} L[a][t] * Linv[t][b]
+    for (int dist = 1; dist < 4; ++dist) {
+        const int b = wave, a2 = wave + dist;
+        if (a2 < 4) {
+            d4 acc = zero;
+            for (int tt = b; tt < a2; ++tt) acc = mm16_nn(T, 16 * a2, 16 * tt, M, 16 * tt, 16 * b, acc);
+            st16(G[wave], 0, 0, acc, 1.0, 0.0);
+        }
+        __syncthreads();
+        if (a2 < 4) {
+            const d4 acc = mm16_nn(M, 16 * a2, 16 * a2, G[wave], 0, 0, zero);
+            st16(M, 16 * a2, 16 * b, acc, -1.0, 0.0);
+        }
+        __syncthreads();
+    }
+    {
+        const int i = t & 63, g = t >> 6;
         for (int q = 0; q < 16; ++q) {
             const int c = g + 4 * q;
-            if (c > j) {
-                if (i >= c) T[i * CD_LD + c] -= lij * (T[c * CD_LD + j] * rinv);
-            } else {
-                const double mjc = M[j * CD_LD + c] * rinv;
-                if (i > j) M[i * CD_LD + c] -= lij * mjc;
-                else if (i == j) Lout[j + 64 * c] = mjc;
-            }
-        }
-        if (g == (j & 3)) {
-            if (i >= j) tile[i + (long)j * ldA] = lij;
-            else Lout[i + 64 * j] = 0.0;          // strictly upper part of L^-1
+            Lout[i + 64 * c] = (i >= c) ? M[c * CD_LD + i] : 0.0;
+            if (i >= c) tile[i + (long)c * ldA] = T[c * CD_LD + i];
         }
     }
-    if (bad && t == 0) atomicMin(status, -6);      // RSLAM_ERR_NOT_SPD
+    if (bad && (t & 63) == 0) atomicMin(status, -6);        // RSLAM_ERR_NOT_SPD
 }
 
 // rows of block b participate in step `step` of a sweep with nblk column blocks?
@@ -635,17 +798,18 @@ int init_kernel_attributes()
     return 0;
 }
 
-void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk,
+void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk, int cap_blocks,
                          double* A, double* Linv, int32_t* status_sel)
 {
     const int rp_blocks = d.RP / 64;
+    const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
     const int row_blocks = d.ldA / 64;
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
-    for (int step = 0; step < rp_blocks; ++step) {
+    for (int step = 0; step < steps; ++step) {
         chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, status_sel);
         panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
-        if (step + 1 < rp_blocks)
-            trail_kernel<<<dim3(row_blocks, rp_blocks - step - 1), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, rp_blocks);
+        if (step + 1 < steps)
+            trail_kernel<<<dim3(row_blocks, steps - step - 1), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, rp_blocks);
     }
 }
 
@@ -658,20 +822,23 @@ __global__ void __launch_bounds__(256)
 xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, const double* __restrict__ A,
                const double* __restrict__ x_in, double* __restrict__ x_out)
 {
-    __shared__ double u[256];
+    // 16 rows x 16 K-slices per workgroup; fixed-order LDS reduction (bitwise reproducible)
+    __shared__ double part[16][17];
     const int K = 64 * sel[slot_nblk];
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int r = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int row = blockIdx.x * 16 + r;
     const double* Y = A + d.RP;
+    const double* u = A + d.RP + d.NP;
     double acc = 0;
-    for (int k0 = 0; k0 < K; k0 += 256) {
-        __syncthreads();
-        if (k0 + threadIdx.x < K) u[threadIdx.x] = A[d.RP + d.NP + (long)(k0 + threadIdx.x) * d.ldA];
-        __syncthreads();
-        const int kn = min(256, K - k0);
-        if (row < d.NP)
-            for (int k = 0; k < kn; ++k) acc += Y[row + (long)(k0 + k) * d.ldA] * u[k];
+    for (int k = sl; k < K; k += 16) acc += Y[row + (long)k * d.ldA] * u[(long)k * d.ldA];
+    part[sl][r] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        double ssum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ssum += part[q][r];
+        x_out[row] = x_in[row] + ssum;
     }
-    if (row < d.NP) x_out[row] = x_in[row] + acc;
 }
 
 __global__ void quat_kernel(const int32_t* __restrict__ sel, int slot_k, double* __restrict__ x, double* __restrict__ T,
@@ -694,7 +861,7 @@ __global__ void quat_kernel(const int32_t* __restrict__ sel, int slot_k, double*
 void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
                          const double* A, const double* x_in, double* x_out, double* T, int compat)
 {
-    xupdate_kernel<<<dim3((d.NP + 255) / 256), dim3(256), 0, s>>>(d, sel, slot_nblk, A, x_in, x_out);
+    xupdate_kernel<<<dim3(d.NP / 16), dim3(256), 0, s>>>(d, sel, slot_nblk, A, x_in, x_out);
     quat_kernel<<<dim3(1), dim3(64), 0, s>>>(sel, slot_k, x_out, T, compat);
 }
 

@@ -78,7 +78,12 @@ struct rslam_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_valid = false;
-    int attr_init = 0;
+    // Factor-sweep launch sizing: the number of block steps enqueued per update follows the
+    // previous frame's inlier counts (+1 block of slack); the device flags an overflow
+    // (STATUS_SWEEP_CAP) and the update stage is then re-run with the full-length sequence.
+    int cap_li = 1 << 20, cap_hi = 1 << 20;
+    const int32_t* last_sup = nullptr;
+    int reruns = 0;
 };
 
 static void invalidate_graph(rslam_ctx* c)
@@ -127,6 +132,7 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->ev_ok = ok;
     memset(&c->times, 0, sizeof(c->times));
     if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0) { delete c; return RSLAM_ERR_HIP; }
+    if (hipMemset(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT) != hipSuccess) { delete c; return RSLAM_ERR_HIP; }
     *out = c;
     return RSLAM_OK;
 }
@@ -352,7 +358,7 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     return RSLAM_OK;
 }
 
-static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, const double* H13,
+static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int cap, const double* H13,
                               const double* z_h, const double* x_in, double* x_out, const double* Pin, double* Pout,
                               int ev_f0, int ev_f1, int ev_r0, int ev_r1)
 {
@@ -361,7 +367,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     int32_t* sel = c->d_sel.p;
     launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p);
     if (ev_f0 >= 0) mark(c, ev_f0);
-    launch_factor_sweep(s, d, sel, slot_nblk, c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
+    launch_factor_sweep(s, d, sel, slot_nblk, cap, c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP > 0) {
         launch_state_update(s, d, sel, slot_k, slot_nblk, c->d_A.p, x_in, x_out, c->d_T.p, c->cfg.compat);
@@ -381,6 +387,7 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     if (!d_sup) return RSLAM_ERR_ARG;
     hipStream_t s = c->stream;
     int32_t* sel = c->d_sel.p;
+    c->last_sup = d_sup;
     if (!c->pht_done) {   // update without a local score pass (supports came from elsewhere)
         launch_innov(s, c->m, c->d_mfeat.p, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
@@ -390,12 +397,12 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     // K5 consensus (Tracking.cpp:507-537)
     launch_select(s, d_sup, c->H, c->d_nhyp.p, c->cfg.adaptive, c->cfg.n_hyp_init, sel);
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
-                     c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p);
+                     c->cfg.sigma_z, c->L, c->cap_li, sel, c->d_li.p, c->d_lilist.p);
     mark(c, EV_SELECT);
     // low-innovation update (ExtendKF.cpp:559-596)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
     launch_gather_w(s, d, c->d_W.p, c->d_rank_of.p, c->d_lilist.p, sel, SEL_K_LI, SEL_NBLK_LI, c->d_A.p);
-    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
+    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, c->cap_li, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
                                 c->d_Ppred.p, c->d_P.p, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0, EV_LI_RANK1);
     if (rc) return rc;
     mark(c, EV_LI_END);
@@ -407,25 +414,56 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h2.p, c->d_hash2.p, nullptr,
                    c->d_H13b.p, c->d_S2.p, c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */);
     launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
-                       c->d_hi.p, c->d_hilist.p, sel);
+                       c->cap_hi, c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
     if (c->RP > 0)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
                    c->d_A.p + c->RP, c->ldA);
-    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
+    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->cap_hi, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);
     return RSLAM_OK;
 }
 
+static int read_status_raw(rslam_ctx* c, int32_t* sel)
+{
+    HIPCHK(hipMemcpyAsync(sel, c->d_sel.p, sizeof(int32_t) * SEL_COUNT, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return RSLAM_OK;
+}
+
+// Synchronise, handle a sweep-cap overflow by re-running the update stage at full length,
+// adapt the caps for the next frame, return the device-side status of the frame.
 static int read_status(rslam_ctx* c, int32_t* sel_host)
 {
     int32_t sel[SEL_COUNT];
-    HIPCHK(hipMemcpyAsync(sel, c->d_sel.p, sizeof(sel), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
+    int rc = read_status_raw(c, sel);
+    if (rc) return rc;
+    const int rp_blocks = c->RP / 64;
+    if (sel[SEL_STATUS] == STATUS_SWEEP_CAP && c->last_sup) {
+        c->cap_li = c->cap_hi = 1 << 20;
+        invalidate_graph(c);
+        ++c->reruns;
+        const int timing = c->timing; c->timing = 0;
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        rc = enqueue_update(c, c->last_sup);
+        c->timing = timing;
+        if (rc) return rc;
+        rc = read_status_raw(c, sel);
+        if (rc) return rc;
+    }
+    if (c->have_meas && c->last_sup && sel[SEL_STATUS] == 0) {
+        auto adapt = [&](int& cap, int nblk) {
+            const int want = nblk + 1 < rp_blocks ? nblk + 1 : rp_blocks;
+            const int cur = cap < rp_blocks ? cap : rp_blocks;
+            if (want > cur || cur - want >= 2) { cap = want; invalidate_graph(c); }
+        };
+        adapt(c->cap_li, sel[SEL_NBLK_LI]);
+        adapt(c->cap_hi, sel[SEL_NBLK_HI]);
+    }
     if (sel_host) memcpy(sel_host, sel, sizeof(sel));
     return sel[SEL_STATUS];
 }
@@ -505,11 +543,12 @@ extern "C" int rslam_fetch_results(rslam_ctx* c, double* x_new, uint8_t* li, uin
     if (!c->have_state) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     int32_t sel[SEL_COUNT];
+    const int status = read_status(c, sel);      // first: it may re-run the update stage (sweep sizing)
+    collect_times(c);
     if (x_new) HIPCHK(hipMemcpyAsync(x_new, c->d_x2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
     if (li && c->L) HIPCHK(hipMemcpyAsync(li, c->d_li.p, c->L, hipMemcpyDeviceToHost, c->stream));
     if (hi && c->L) HIPCHK(hipMemcpyAsync(hi, c->d_hi.p, c->L, hipMemcpyDeviceToHost, c->stream));
-    const int status = read_status(c, sel);
-    collect_times(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (best_hyp) *best_hyp = sel[SEL_BEST_HYP];
     if (best_support) *best_support = sel[SEL_BEST_SUPPORT];
     if (hyps_evaluated) *hyps_evaluated = sel[SEL_HYPS_EVALUATED];
