@@ -204,10 +204,17 @@ int rslam_k_gemm_nt(rslam_ctx* ctx, int32_t m, int32_t n, int32_t k,
 /* Peak-rate probe: issues back-to-back v_mfma_f64_16x16x4_f64 from every CU
  * and returns the measured TFLOP/s (prints nothing). */
 int rslam_k_mfma_f64_peak(rslam_ctx* ctx, double* tflops);
-/* Same probe with waves_per_simd resident waves per SIMD; also reports the
- * shader cycles one SIMD spends per MFMA and the in-kernel clock (either may be NULL). */
-int rslam_k_mfma_f64_probe(rslam_ctx* ctx, int32_t waves_per_simd, double* tflops,
+/* Same probe with (waves_and_mode & 15) resident waves per SIMD and instruction mix
+ * (waves_and_mode >> 4): 0 = 4 accumulators of 16x16x4, 1 = 8 accumulators, 2 = 4x4x4_4b;
+ * also reports the shader cycles one SIMD spends per MFMA and the in-kernel clock
+ * (either may be NULL). */
+int rslam_k_mfma_f64_probe(rslam_ctx* ctx, int32_t waves_and_mode, double* tflops,
                            double* cycles_per_mfma, double* clock_mhz);
+/* One v_mfma_f64_4x4x4_4b_f64 on caller-supplied per-lane operands (host pointers, 64 doubles
+ * each): d = mfma(a, b, c) with the given CBSZ / ABID.  Unit test of the operand lane maps the
+ * tile engine relies on. */
+int rslam_k_mfma4_raw(rslam_ctx* ctx, int32_t cbsz, int32_t abid, const double* a, const double* b,
+                      const double* c, double* d);
 /* Streaming-copy probe: measured HBM GB/s for a bytes-sized device copy. */
 int rslam_k_hbm_copy_peak(rslam_ctx* ctx, int64_t bytes, double* gbps);
 

@@ -48,6 +48,7 @@ SYMBOLS = {
                                   C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32]),
     "rslam_k_mfma_f64_peak": (C.c_int, [C.c_void_p, _dp]),
     "rslam_k_mfma_f64_probe": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "rslam_k_mfma4_raw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
     "rslam_k_hbm_copy_peak": (C.c_int, [C.c_void_p, C.c_int64, _dp]),
 }
 
@@ -219,11 +220,17 @@ class RslamHip:
         _chk(lib().rslam_k_mfma_f64_peak(self._h, C.byref(v)), "rslam_k_mfma_f64_peak")
         return v.value
 
-    def mfma_f64_probe(self, waves_per_simd=1):
+    def mfma_f64_probe(self, waves_per_simd=1, mode=0):
         t, cy, mhz = C.c_double(), C.c_double(), C.c_double()
-        _chk(lib().rslam_k_mfma_f64_probe(self._h, waves_per_simd, C.byref(t), C.byref(cy), C.byref(mhz)),
+        _chk(lib().rslam_k_mfma_f64_probe(self._h, waves_per_simd + 16 * mode, C.byref(t), C.byref(cy), C.byref(mhz)),
              "rslam_k_mfma_f64_probe")
         return dict(tflops=t.value, cycles_per_mfma=cy.value, clock_mhz=mhz.value)
+
+    def mfma4_raw(self, a, b, c, cbsz=0, abid=0):
+        a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64)
+        c = np.ascontiguousarray(c, np.float64); d = np.zeros(64)
+        _chk(lib().rslam_k_mfma4_raw(self._h, cbsz, abid, _p(a), _p(b), _p(c), _p(d)), "rslam_k_mfma4_raw")
+        return d
 
     def hbm_copy_peak(self, nbytes=1 << 30):
         v = C.c_double()

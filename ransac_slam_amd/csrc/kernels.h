@@ -82,7 +82,8 @@ int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kern
 int init_kernel_attributes2();
 void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,
                     const double* B, long ldb, double beta, double* C, long ldc);
-void launch_mfma_probe(hipStream_t s, int blocks, int iters, double* out, unsigned long long* stamps);
+void launch_mfma_probe(hipStream_t s, int blocks, int iters, int mode, double* out, unsigned long long* stamps);
+void launch_mfma4_raw(hipStream_t s, int cbsz, int abid, const double* a, const double* b, const double* c, double* d);
 void launch_copy_probe(hipStream_t s, const double* src, double* dst, long n);
 
 }  // namespace rslam

@@ -1025,30 +1025,73 @@ int init_kernel_attributes2()
 // ---------------------------------------------------------------------------
 // Probes: FP64 MFMA issue rate and streaming-copy bandwidth of this device.
 // ---------------------------------------------------------------------------
+// mode 0: 4 independent 16x16x4 accumulators per wave; 1: 8 accumulators; 2: v_mfma_f64_4x4x4_4b (4 x 512 flop)
 __global__ void __launch_bounds__(256)
-mfma_probe_kernel(int iters, double* out, unsigned long long* stamps)
+mfma_probe_kernel(int iters, int mode, double* out, unsigned long long* stamps)
 {
     const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    if (mode == 0) {
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+        }
+    } else if (mode == 1) {
+        for (int i = 0; i < iters; i += 2) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c5, 0, 0, 0);
+            c6 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c6, 0, 0, 0);
+            c7 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c7, 0, 0, 0);
+        }
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s1, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s2, 0, 0, 0);
+            s3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s3, 0, 0, 0);
+        }
     }
-    const d4 sum = c0 + c1 + c2 + c3;
-    asm volatile("" :: "v"(sum[0]));
+    const d4 sum = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    const double ssum = sum[0] + s0 + s1 + s2 + s3;
+    asm volatile("" :: "v"(ssum));
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    if (sum[0] == -1.0) out[blockIdx.x * 256 + threadIdx.x] = sum[1] + sum[2] + sum[3];
+    if (ssum == -1.0) out[blockIdx.x * 256 + threadIdx.x] = sum[1] + sum[2] + sum[3];
     if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
 }
 
-void launch_mfma_probe(hipStream_t s, int blocks, int iters, double* out, unsigned long long* stamps)
+void launch_mfma_probe(hipStream_t s, int blocks, int iters, int mode, double* out, unsigned long long* stamps)
 {
-    mfma_probe_kernel<<<dim3(blocks), dim3(256), 0, s>>>(iters, out, stamps);
+    mfma_probe_kernel<<<dim3(blocks), dim3(256), 0, s>>>(iters, mode, out, stamps);
+}
+
+// one v_mfma_f64_4x4x4_4b_f64 with caller-chosen per-lane operands (layout discovery / unit test)
+template <int CBSZ, int ABID>
+__global__ void __launch_bounds__(64)
+mfma4_raw_kernel(const double* a, const double* b, const double* c, double* d)
+{
+    const int l = threadIdx.x;
+    d[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[l], b[l], c[l], CBSZ, ABID, 0);
+}
+
+void launch_mfma4_raw(hipStream_t s, int cbsz, int abid, const double* a, const double* b, const double* c, double* d)
+{
+    if (cbsz == 0) mfma4_raw_kernel<0, 0><<<1, 64, 0, s>>>(a, b, c, d);
+    else if (cbsz == 2 && abid == 0) mfma4_raw_kernel<2, 0><<<1, 64, 0, s>>>(a, b, c, d);
+    else if (cbsz == 2 && abid == 1) mfma4_raw_kernel<2, 1><<<1, 64, 0, s>>>(a, b, c, d);
+    else if (cbsz == 2 && abid == 2) mfma4_raw_kernel<2, 2><<<1, 64, 0, s>>>(a, b, c, d);
+    else if (cbsz == 2 && abid == 3) mfma4_raw_kernel<2, 3><<<1, 64, 0, s>>>(a, b, c, d);
+    else if (cbsz == 1 && abid == 0) mfma4_raw_kernel<1, 0><<<1, 64, 0, s>>>(a, b, c, d);
+    else if (cbsz == 1 && abid == 1) mfma4_raw_kernel<1, 1><<<1, 64, 0, s>>>(a, b, c, d);
 }
 
 __global__ void __launch_bounds__(256)

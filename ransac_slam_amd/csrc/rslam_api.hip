@@ -721,29 +721,31 @@ extern "C" int rslam_k_gemm_nt(rslam_ctx* c, int32_t m, int32_t n, int32_t k, do
     return RSLAM_OK;
 }
 
-// waves_per_simd = 1 or 2; cycles_per_mfma and clock_mhz (in-kernel, s_memtime / s_memrealtime) may be NULL
-extern "C" int rslam_k_mfma_f64_probe(rslam_ctx* c, int32_t waves_per_simd, double* tflops, double* cycles_per_mfma,
+// waves_per_simd 1..8; mode in the high bits: waves_per_simd + 16 * mode (0: 4 accumulators of 16x16x4,
+// 1: 8 accumulators, 2: 4x4x4_4b); cycles_per_mfma and clock_mhz (s_memtime / s_memrealtime) may be NULL
+extern "C" int rslam_k_mfma_f64_probe(rslam_ctx* c, int32_t waves_and_mode, double* tflops, double* cycles_per_mfma,
                                       double* clock_mhz)
 {
-    if (!c || !tflops || waves_per_simd < 1 || waves_per_simd > 8) return RSLAM_ERR_ARG;
+    const int waves_per_simd = waves_and_mode & 15, mode = waves_and_mode >> 4;
+    if (!c || !tflops || waves_per_simd < 1 || waves_per_simd > 8 || mode < 0 || mode > 2) return RSLAM_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, c->device));
     const int blocks = prop.multiProcessorCount * waves_per_simd, iters = 20000;
     if (c->d_probe.ensure((size_t)blocks * 256 + 8) < 0) return RSLAM_ERR_HIP;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(c->d_probe.p + (size_t)blocks * 256);
-    launch_mfma_probe(c->stream, blocks, 2000, c->d_probe.p, nullptr);       // warm-up
+    launch_mfma_probe(c->stream, blocks, 2000, mode, c->d_probe.p, nullptr);       // warm-up
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     HIPCHK(hipEventRecord(a, c->stream));
-    launch_mfma_probe(c->stream, blocks, iters, c->d_probe.p, stamps);
+    launch_mfma_probe(c->stream, blocks, iters, mode, c->d_probe.p, stamps);
     HIPCHK(hipEventRecord(b, c->stream));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     unsigned long long st[2] = {0, 0};
     HIPCHK(hipMemcpy(st, stamps, sizeof(st), hipMemcpyDeviceToHost));
-    const double flops = (double)blocks * 4.0 * (double)iters * 4.0 * 2048.0;   // 16x16x4 MFMA = 2048 flop
+    const double flops = (double)blocks * 4.0 * (double)iters * 4.0 * (mode == 2 ? 512.0 : 2048.0);   // per MFMA
     *tflops = flops / ((double)ms * 1e-3) * 1e-12;
     // one SIMD executed waves_per_simd * 4 * iters MFMAs during st[0] shader cycles
     if (cycles_per_mfma) *cycles_per_mfma = (double)st[0] / ((double)iters * 4.0 * waves_per_simd);
@@ -754,6 +756,23 @@ extern "C" int rslam_k_mfma_f64_probe(rslam_ctx* c, int32_t waves_per_simd, doub
 extern "C" int rslam_k_mfma_f64_peak(rslam_ctx* c, double* tflops)
 {
     return rslam_k_mfma_f64_probe(c, 2, tflops, nullptr, nullptr);
+}
+
+// d[64] = one v_mfma_f64_4x4x4_4b_f64(a[64], b[64], c[64]) with the given CBSZ/ABID (host pointers)
+extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const double* a, const double* b,
+                                 const double* cc, double* d)
+{
+    if (!c || !a || !b || !cc || !d) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_probe.ensure(256) < 0) return RSLAM_ERR_HIP;
+    double* p = c->d_probe.p;
+    HIPCHK(hipMemcpy(p, a, 512, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p + 64, b, 512, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p + 128, cc, 512, hipMemcpyHostToDevice));
+    launch_mfma4_raw(c->stream, cbsz, abid, p, p + 64, p + 128, p + 192);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(d, p + 192, 512, hipMemcpyDeviceToHost));
+    return RSLAM_OK;
 }
 
 extern "C" int rslam_k_hbm_copy_peak(rslam_ctx* c, int64_t bytes, double* gbps)

@@ -6,15 +6,25 @@
 // has this shape (covariance rank-r update Y*Y^T, panel solve X*Linv^T,
 // trailing update L_ik*L_jk^T), so there is exactly one MFMA inner loop.
 //
-// v_mfma_f64_16x16x4_f64: lane l supplies A[i = l&15][k = l>>4] and
-// B[k = l>>4][j = l&15]; the 4 results of lane l are C[(l>>4) + 4*reg][l&15].
-// Each wave computes a 32 x 32 sub-tile as 2 x 2 MFMA tiles (4 independent
-// accumulators keep the 64-cycle matrix pipe back to back).
+// Instruction choice (measured on MI355X, scripts/probe.py): v_mfma_f64_16x16x4_f64
+// issues at ~100 cycles per 2048 flop however many waves are resident (49 TF/s
+// chip-wide), v_mfma_f64_4x4x4_4b_f64 at 16-20 cycles per 512 flop (60-75 TF/s,
+// the 78.6 TF/s datasheet rate), so the engine is built on the 4x4x4 form.
+// Its lane maps (verified by tests/test_gpu_parity.py::test_mfma4_lane_map):
+//   A: lane l supplies A_blk[i][k],  B: B_blk[k][j],  with k = l>>4, blk = (l>>2)&3, i|j = l&3
+//   D: lane l receives D_blk[i][j]  with i = l>>4, blk = (l>>2)&3, j = l&3
+// i.e. four independent 4x4x4 products per instruction (the CBSZ/ABID operand
+// broadcast is ignored for f64).  A 16 x 16 x 4 product needs all 16 (row-block,
+// column-block) pairs: 4 instructions on the same A fragment and the B fragment
+// rotated by 0/4/8/12 lanes inside each 16-lane row (DPP row_ror: VALU work that
+// overlaps the matrix pipe), instead of extra LDS reads.  The per-lane operand
+// fetch is the same as for 16x16x4 (row = l & 15, k = l >> 4).
 //
-// LDS image per operand and buffer: [KC][LDS_LD] doubles, row index contiguous,
-// so global->LDS is a straight 16-byte copy and every ds_read_b64 of a fragment
-// touches 16 consecutive doubles per k.  LDS_LD = 80 doubles (= 160 dwords = 32
-// mod 64 banks) puts the two k-rows a 32-lane half reads on disjoint banks.
+// Each wave computes a 32 x 32 sub-tile as 2 x 2 tiles of 16 x 16 (16 independent
+// accumulators).  LDS image per operand and buffer: [KC][LDS_LD] doubles, row index
+// contiguous, so global->LDS is a straight 16-byte copy and every ds_read_b64 of
+// a fragment touches 16 consecutive doubles per k.  LDS_LD = 80 doubles (= 160
+// dwords = 32 mod 64 banks) puts the two k-rows a 32-lane half reads on disjoint banks.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -59,6 +69,44 @@ __device__ __forceinline__ void tg_store_chunk(double* As, double* Bs, const Til
     }
 }
 
+// rotate a double by N lanes inside every 16-lane row: lane i receives lane (i - N) mod 16
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + N, 0xF, 0xF, true);   // every lane has a source: no "old" operand
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// B fragment of one 16-column tile with its three block rotations
+struct BFrag { double r0, r1, r2, r3; };
+__device__ __forceinline__ BFrag tg_rotations(double b)
+{
+    BFrag f;
+#if defined(TG_FAKE_ROT)        // timing experiment only (wrong results): no DPP work
+    f.r0 = b; f.r1 = b; f.r2 = b; f.r3 = b;
+#else
+    f.r0 = b; f.r1 = row_ror_f64<4>(b); f.r2 = row_ror_f64<8>(b); f.r3 = row_ror_f64<12>(b);
+#endif
+    return f;
+}
+
+// acc[t] accumulates, for lane (i = l>>4, blk = (l>>2)&3, j = l&3), the element
+//   row 4*blk + i,  column 4*((blk - t) & 3) + j   of a 16 x 16 tile.
+__device__ __forceinline__ void tg_mma_16x16x4(double a, const BFrag& b, d4& acc)
+{
+    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r1, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r2, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r3, acc[3], 0, 0, 0);
+}
+
+// One staged K chunk.  Software pipelined by hand: the fragments of k-step s+1 are read
+// from LDS while the 16 MFMAs of k-step s occupy the matrix pipe.  The three rotated copies
+// of each B fragment are read straight from LDS with rotated per-lane addresses (an LDS read
+// is asynchronous; the DPP alternative costs 12 VALU issues per k-step on the same SIMD the
+// MFMAs issue from -- measured 15 % slower).
 __device__ __forceinline__ void tg_compute_chunk(const double* As, const double* Bs, d4 (&acc)[2][2])
 {
     const int lane = threadIdx.x & 63;
@@ -66,15 +114,28 @@ __device__ __forceinline__ void tg_compute_chunk(const double* As, const double*
     const int wm = wave >> 1, wn = wave & 1;
     const int kq = lane >> 4, ij = lane & 15;
     const double* ap = As + kq * TG_LD + wm * 32 + ij;
-    const double* bp = Bs + kq * TG_LD + wn * 32 + ij;
+    const double* bb = Bs + kq * TG_LD + wn * 32;
+    const double* bp0 = bb + ij;
+    const double* bp1 = bb + ((ij - 4) & 15);
+    const double* bp2 = bb + ((ij - 8) & 15);
+    const double* bp3 = bb + ((ij - 12) & 15);
+    double a0 = ap[0], a1 = ap[16];
+    BFrag b0 = { bp0[0], bp1[0], bp2[0], bp3[0] }, b1 = { bp0[16], bp1[16], bp2[16], bp3[16] };
 #pragma unroll
     for (int kk = 0; kk < TG_KC; kk += 4) {
-        const double a0 = ap[kk * TG_LD], a1 = ap[kk * TG_LD + 16];
-        const double b0 = bp[kk * TG_LD], b1 = bp[kk * TG_LD + 16];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        double na0 = 0, na1 = 0;
+        BFrag nb0 = {0, 0, 0, 0}, nb1 = {0, 0, 0, 0};
+        if (kk + 4 < TG_KC) {
+            const int o = (kk + 4) * TG_LD;
+            na0 = ap[o]; na1 = ap[o + 16];
+            nb0.r0 = bp0[o]; nb0.r1 = bp1[o]; nb0.r2 = bp2[o]; nb0.r3 = bp3[o];
+            nb1.r0 = bp0[o + 16]; nb1.r1 = bp1[o + 16]; nb1.r2 = bp2[o + 16]; nb1.r3 = bp3[o + 16];
+        }
+        tg_mma_16x16x4(a0, b0, acc[0][0]);
+        tg_mma_16x16x4(a0, b1, acc[0][1]);
+        tg_mma_16x16x4(a1, b0, acc[1][0]);
+        tg_mma_16x16x4(a1, b1, acc[1][1]);
+        if (kk + 4 < TG_KC) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
     }
 }
 
@@ -122,15 +183,16 @@ __device__ __forceinline__ void tg_acc_to_lds(const d4 (&acc)[2][2], double* Cs,
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = wm * 32 + mi * 16 + (lane >> 4) + 4 * reg;
-                const int col = wn * 32 + ni * 16 + (lane & 15);
-                Cs[col * TS_LD + row] = acc[mi][ni][reg] * scale;
+            for (int t = 0; t < 4; ++t) {
+                const int row = wm * 32 + mi * 16 + 4 * blk + i;
+                const int col = wn * 32 + ni * 16 + 4 * ((blk - t) & 3) + j;
+                Cs[col * TS_LD + row] = acc[mi][ni][t] * scale;
             }
 }
 

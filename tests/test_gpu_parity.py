@@ -88,6 +88,24 @@ def test_mfma_gemm_nt_matches_torch(hip):
     ctx.close()
 
 
+def test_mfma4_lane_map(hip):
+    """Operand / result lane maps of v_mfma_f64_4x4x4_4b_f64 that tile_gemm.h is built on."""
+    ctx = hip.RslamHip(default_config())
+    rng = np.random.default_rng(9)
+    a, b, c = rng.normal(size=64), rng.normal(size=64), rng.normal(size=64)
+    d = ctx.mfma4_raw(a, b, c)
+    lanes = np.arange(64)
+    want = np.zeros(64)
+    for l in lanes:
+        i, blk, j = l >> 4, (l >> 2) & 3, l & 3
+        acc = c[l]
+        for k in range(4):
+            acc += a[16 * k + 4 * blk + i] * b[16 * k + 4 * blk + j]
+        want[l] = acc
+    assert np.allclose(d, want, rtol=1e-14, atol=1e-14)
+    ctx.close()
+
+
 def test_rank_update_kernel_matches_torch(hip):
     import torch
     ctx = hip.RslamHip(default_config())
