@@ -29,5 +29,21 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_EXAMPLE = os.path.join(HOST_DIR, "track_frame_example")
+
+
+def build_host_example(force=False):
+    """C++ host-side mirror of the reference interface (ransac_slam_hip.hpp) + example driver."""
+    srcs = [os.path.join(HOST_DIR, "track_frame_example.cpp"), os.path.join(HOST_DIR, "ransac_slam_hip.hpp")]
+    if (not force and os.path.exists(HOST_EXAMPLE)
+            and os.path.getmtime(HOST_EXAMPLE) >= max(os.path.getmtime(f) for f in srcs + [LIB])):
+        return HOST_EXAMPLE
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.dirname(HERE), srcs[0], "-o", HOST_EXAMPLE,
+                           "-L", HERE, "-lrslam_hip", "-Wl,-rpath,$ORIGIN/.."])
+    return HOST_EXAMPLE
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host_example())

@@ -1,0 +1,193 @@
+// ransac_slam_hip.hpp -- host-side mirror of the reference's interface for the hot path,
+// written above the C ABI (include/rslam.h).  The reference is compiled C++ whose path
+// is reached through ExtendKF / Tracking member calls that communicate via public data
+// members (include/ransac_slam/ExtendKF.h:154-169, Tracking.h:19-48); this header keeps
+// the same names, argument meaning and call order so that System::TrackRunning
+// (src/System.cpp:117-129) can switch by changing two types.  Eigen is replaced by two
+// minimal column-major containers (the image has no Eigen); with Eigen available the
+// members map 1:1 onto Eigen::VectorXd / MatrixXd buffers.
+//
+// Error behaviour: the reference exit()s or Eigen-asserts; these methods throw
+// ransac_slam_hip::Error carrying the RSLAM_ERR_* code instead of killing the ROS node.
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rslam.h"
+
+namespace ransac_slam_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& where) : std::runtime_error(where + ": " + rslam_error_string(c)), code(c) {}
+};
+
+// column-major dense matrix / vector with the few members the adapter needs
+struct MatrixXd {
+    int r = 0, c = 0;
+    std::vector<double> v;
+    void resize(int rows, int cols) { r = rows; c = cols; v.assign((size_t)rows * cols, 0.0); }
+    int rows() const { return r; }
+    int cols() const { return c; }
+    double& operator()(int i, int j) { return v[(size_t)j * r + i]; }
+    double operator()(int i, int j) const { return v[(size_t)j * r + i]; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
+};
+struct VectorXd {
+    std::vector<double> v;
+    void resize(int n) { v.assign((size_t)n, 0.0); }
+    int rows() const { return (int)v.size(); }
+    double& operator()(int i) { return v[(size_t)i]; }
+    double operator()(int i) const { return v[(size_t)i]; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
+};
+
+// CamParam, System.h:69-82 (hot fields)
+struct CamParam { double k1, k2; int nRows, nCols; double Cx, Cy, f, dx, dy; };
+
+// struct Feature, ExtendKF.h:14-42 (hot fields; the dense 2 x n H is never materialised)
+struct Feature {
+    std::string type;                    // "inversedepth" | "cartesian"
+    bool individually_compatible = false;
+    bool low_innovation_inlier = false;
+    bool high_innovation_inlier = false;
+    VectorXd z;                          // 2 entries when matched, empty otherwise
+    VectorXd h;                          // 2 entries when predicted visible, empty otherwise
+    MatrixXd S;                          // 2 x 2
+};
+
+// ExtendKF members and methods on the hot path (ExtendKF.h:154-169)
+class ExtendKF {
+public:
+    std::vector<Feature> features_info;
+    CamParam* cam = nullptr;
+    VectorXd x_k_k, x_k_km1;
+    MatrixXd p_k_k, p_k_km1;
+    double std_z = 1.0;
+
+    // n_draws: length of the draw list handed to the RANSAC loop per frame (>= the
+    // reference's initial n_hyp = 1000, Tracking.cpp:357)
+    ExtendKF(CamParam* param, int device = 0, int compat = 1, int n_draws = 1400)
+        : cam(param), n_draws_(n_draws)
+    {
+        rslam_config cfg{};
+        cfg.cam.k1 = param->k1; cfg.cam.k2 = param->k2; cfg.cam.Cx = param->Cx; cfg.cam.Cy = param->Cy;
+        cfg.cam.f = param->f; cfg.cam.dx = param->dx; cfg.cam.dy = param->dy;
+        cfg.cam.nRows = param->nRows; cfg.cam.nCols = param->nCols;
+        cfg.sigma_z = std_z; cfg.p_success = 0.99; cfg.n_hyp_init = 1000; cfg.chi2_gate = 5.9915;
+        cfg.compat = compat; cfg.adaptive = 1; cfg.dedup = 1;
+        const int rc = rslam_create(&cfg, device, &ctx_);
+        if (rc) throw Error(rc, "rslam_create");
+    }
+    ~ExtendKF() { if (ctx_) rslam_destroy(ctx_); }
+    ExtendKF(const ExtendKF&) = delete;
+    ExtendKF& operator=(const ExtendKF&) = delete;
+
+    rslam_ctx* ctx() { return ctx_; }
+    int n_draws() const { return n_draws_; }
+
+    // Partial update using low-innovation inliers (ExtendKF.cpp:559-596).  The device
+    // already ran both updates inside Tracking::ransac_hypotheses; this publishes nothing
+    // new (the reference's intermediate x_k_k/p_k_k is overwritten two calls later).
+    void ekf_update_li_inliers() {}
+    // Partial update using high-innovation inliers (ExtendKF.cpp:640-678): publish x_k_k,
+    // and p_k_k when something on the host needs it (Map management reads it each frame).
+    void ekf_update_hi_inliers(bool fetch_covariance = true)
+    {
+        const int n = x_k_km1.rows();
+        x_k_k.resize(n);
+        int rc = rslam_fetch_state(ctx_, x_k_k.data());
+        if (rc) throw Error(rc, "rslam_fetch_state");
+        if (fetch_covariance) {
+            p_k_k.resize(n, n);
+            rc = rslam_fetch_cov(ctx_, p_k_k.data());
+            if (rc) throw Error(rc, "rslam_fetch_cov");
+        }
+    }
+
+private:
+    rslam_ctx* ctx_ = nullptr;
+    int n_draws_;
+};
+
+// Tracking methods on the hot path (Tracking.h:19-48)
+class Tracking {
+public:
+    explicit Tracking(ExtendKF* m_ExtendKF) : mT_ExtendKF(m_ExtendKF) {}
+
+    // First part of Tracking::search_IC_matches (Tracking.cpp:35-44): h_i, Jacobians, S_i.
+    // The patch warp and NCC matching (Tracking.cpp:46-69) stay on the host and consume
+    // features_info[i].h / .S exactly as before.
+    void search_IC_matches_predict()
+    {
+        ExtendKF& k = *mT_ExtendKF;
+        const int L = (int)k.features_info.size();
+        type_.resize(L); offset_.resize(L);
+        int off = 13;
+        for (int i = 0; i < L; ++i) {
+            const bool id = (k.features_info[i].type == "inversedepth");
+            type_[i] = id ? RSLAM_FEAT_INVERSE_DEPTH : RSLAM_FEAT_CARTESIAN;
+            offset_[i] = off; off += id ? 6 : 3;
+        }
+        rslam_layout lay{off, L, type_.data(), offset_.data()};
+        std::vector<double> h(2 * (size_t)L + 1), S(4 * (size_t)L + 1);
+        std::vector<uint8_t> vis((size_t)L + 1);
+        const int rc = rslam_predict(k.ctx(), &lay, k.x_k_km1.data(), k.p_k_km1.data(), h.data(), vis.data(), S.data());
+        if (rc) throw Error(rc, "rslam_predict");
+        for (int i = 0; i < L; ++i) {
+            Feature& f = k.features_info[i];
+            if (!vis[i]) continue;                      // "if(hi.rows() != 0)", ExtendKF.cpp:77
+            f.h.resize(2); f.h(0) = h[2 * i]; f.h(1) = h[2 * i + 1];
+            f.S.resize(2, 2);
+            for (int q = 0; q < 4; ++q) f.S.v[q] = S[4 * i + q];
+        }
+    }
+
+    // Tracking::ransac_hypotheses (Tracking.cpp:352-539).  One device call runs the RANSAC
+    // stage, both EKF updates and the rescue (System.cpp:120-129) with P resident in HBM.
+    // The reference draws rand()/RAND_MAX per iteration (ExtendKF.cpp:230); the draws are
+    // generated up front from the same std::rand stream.
+    void ransac_hypotheses()
+    {
+        ExtendKF& k = *mT_ExtendKF;
+        const int L = (int)k.features_info.size();
+        std::vector<double> z(2 * (size_t)L + 1, 0.0), draws((size_t)k.n_draws());
+        std::vector<uint8_t> ic((size_t)L + 1, 0);
+        li_.assign((size_t)L + 1, 0); hi_.assign((size_t)L + 1, 0);
+        for (int i = 0; i < L; ++i) {
+            const Feature& f = k.features_info[i];
+            ic[i] = f.individually_compatible ? 1 : 0;
+            if (ic[i]) { z[2 * i] = f.z(0); z[2 * i + 1] = f.z(1); }
+        }
+        if (!replay_draws.empty()) draws = replay_draws;          // deterministic replay (tests)
+        else for (double& d : draws) d = (double)std::rand() / ((double)RAND_MAX + 1.0);
+        std::vector<double> x_new((size_t)k.x_k_km1.rows());
+        const int rc = rslam_ransac_update(k.ctx(), z.data(), ic.data(), draws.data(), (int)draws.size(), x_new.data(),
+                                           nullptr /* P stays resident */, li_.data(), hi_.data(), &best_hyp,
+                                           &best_support, &hyps_evaluated);
+        if (rc) throw Error(rc, "rslam_ransac_update");
+        for (int i = 0; i < L; ++i) k.features_info[i].low_innovation_inlier = li_[i] != 0;
+    }
+
+    // Tracking::rescue_hi_inliers (Tracking.cpp:574-597): flags were produced on the device.
+    void rescue_hi_inliers()
+    {
+        ExtendKF& k = *mT_ExtendKF;
+        for (size_t i = 0; i < k.features_info.size(); ++i) k.features_info[i].high_innovation_inlier = hi_[i] != 0;
+    }
+
+    int32_t best_hyp = -1, best_support = 0, hyps_evaluated = 0;
+    std::vector<double> replay_draws;    // when set, used instead of the std::rand stream
+
+private:
+    ExtendKF* mT_ExtendKF;
+    std::vector<uint8_t> type_, li_, hi_;
+    std::vector<int32_t> offset_;
+};
+
+}  // namespace ransac_slam_hip
