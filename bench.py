@@ -89,10 +89,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # rehearsal hooks (one-GPU box): several ranks on one device over gloo
+    if os.environ.get("RSLAM_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["RSLAM_FORCE_DEVICE"])
+    backend = os.environ.get("RSLAM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     wl = WORKLOADS[args.workload]
     H_local = wl["H"]

@@ -558,171 +558,207 @@ __device__ __forceinline__ double rsqrt_f64(double d)
     return y;
 }
 
-// ---- 64 x 64 diagonal block: 16 x 16 sub-blocked Cholesky + inverse -------------
-// The block lives in LDS (column-major, ld 65).  Only the four 16 x 16 diagonal
-// sub-blocks go through scalar pivot steps (one wave, register resident, LDS
-// broadcast vector, no workgroup barrier inside); every other sub-block operation
-// -- sub-panel solve X * Li^T, trailing update, and the off-diagonal blocks of
-// L^-1 -- is a 16x16x16 product on v_mfma_f64_16x16x4_f64.
+// ---- 64 x 64 diagonal block: Cholesky factor and its inverse, 4 pivots per step -------
+// The serial pivot chain is what bounds the whole sweep, so it is cut four-fold: one step
+// eliminates a 4 x 4 pivot block.
+//   A  every lane computes the 4 x 4 Cholesky factor of the pivot block in closed form
+//      (10 broadcast LDS reads, 4 reciprocal square roots);
+//   B  64 lanes solve their row of the 64 x 4 panel X = A(:,p) L4^-T, 64 lanes their column
+//      of the pivot rows of the running inverse, L4^-1 M(p,:), by 4-step substitution;
+//   C  the trailing matrix and the running inverse live in MFMA accumulator tiles
+//      (16 x 16, ten lower tiles each, spread over the 4 waves); a rank-4 update of a tile
+//      is exactly ONE v_mfma_f64_16x16x4_f64 (K = 4) with operands read from the panel;
+//   D  the owners publish the next pivot's 4 columns / 4 inverse rows to LDS.
+// Two barriers per 4 pivots; L and L^-1 are collected in LDS and written once at the end
+// (a global store inside the loop would put a vmcnt(0) wait into every barrier).
 constexpr int CD_LD = 65;
 
-// wave-level 16 x 16 Cholesky + inverse of the sub-block at (o,o) of T.
-// Lane i (< 16) owns row i: 16 registers that hold A(i,c) until column c is eliminated and
-// (L^-1)(i,c) afterwards.  Everything a pivot step shares -- the pivot, L(c,j) of the rows
-// below, row j of the partial inverse -- is a (static lane, static register) pair, so it is
-// broadcast with v_readlane through SGPRs: no LDS round trip on the 16-pivot chain.
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
+struct Chol4 { double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3; bool bad; };
 
-__device__ __forceinline__ bool factor16(double* T, double* M, int o)
+__device__ __forceinline__ Chol4 chol4(const double* Tc /* [4][64] */, int p0)
 {
-    const int i = threadIdx.x & 63;          // rows 16..63 compute along harmlessly and store nothing
-    const int ir = i & 15;
-    double val[16], lcol[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        val[c] = (ir >= c) ? T[(o + c) * CD_LD + o + ir] : T[(o + ir) * CD_LD + o + c];
-        lcol[c] = 0.0;
-    }
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double dj = readlane_f64(val[j], j);
-        bad = bad || !(dj > 0.0);
-        const double rinv = rsqrt_f64(dj);
-        const double lij = val[j] * rinv;            // L(i,j) for i >= j
-        const double nl = -lij;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            if (c > j) {                             // Schur update of A(i,c): needs L(c,j) = A(c,j) * rinv
-                const double lcj = readlane_f64(val[j], c) * rinv;
-                const double upd = fma(nl, lcj, val[c]);
-                val[c] = (ir >= c) ? upd : val[c];
-            } else if (c < j) {                      // row operation on L^-1: needs (L^-1)(j,c) after scaling
-                const double mjc = readlane_f64(val[c], j) * rinv;
-                const double upd = fma(nl, mjc, val[c]);
-                val[c] = (ir > j) ? upd : ((ir == j) ? mjc : val[c]);
-            }
-        }
-        lcol[j] = lij;
-        val[j] = (ir == j) ? rinv : ((ir > j) ? nl * rinv : 0.0);
-    }
-    if (i < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            M[(o + c) * CD_LD + o + i] = (i >= c) ? val[c] : 0.0;      // L^-1 block, upper part zero
-            T[(o + c) * CD_LD + o + i] = (i >= c) ? lcol[c] : 0.0;     // L block, upper part zero
-        }
-    }
-    return bad;
-}
-
-// 16x16x16 products on sub-blocks of LDS matrices (ld CD_LD, column-major)
-__device__ __forceinline__ d4 mm16_nt(const double* P, int pr, int pc, const double* Q, int qr, int qc, d4 acc)
-{   // acc += P[pr.., pc..] * Q[qr.., qc..]^T
-    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4) {
-        const double a = P[(pc + kk + kq) * CD_LD + pr + i];
-        const double b = Q[(qc + kk + kq) * CD_LD + qr + i];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-__device__ __forceinline__ d4 mm16_nn(const double* P, int pr, int pc, const double* Q, int qr, int qc, d4 acc)
-{   // acc += P[pr.., pc..] * Q[qr.., qc..]
-    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4) {
-        const double a = P[(pc + kk + kq) * CD_LD + pr + i];
-        const double b = Q[(qc + i) * CD_LD + qr + kk + kq];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-// C[cr.., cc..] = alpha * acc + beta * C   (lane l holds rows (l>>4)+4*reg, column l&15)
-__device__ __forceinline__ void st16(double* C, int cr, int cc, d4 acc, double alpha, double beta)
-{
-    const int l = threadIdx.x & 63;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        double* p = C + (cc + (l & 15)) * CD_LD + cr + (l >> 4) + 4 * reg;
-        *p = (beta != 0.0) ? alpha * acc[reg] + beta * (*p) : alpha * acc[reg];
-    }
+    const double d00 = Tc[0 * 64 + p0], d10 = Tc[0 * 64 + p0 + 1], d20 = Tc[0 * 64 + p0 + 2], d30 = Tc[0 * 64 + p0 + 3];
+    const double d11 = Tc[1 * 64 + p0 + 1], d21 = Tc[1 * 64 + p0 + 2], d31 = Tc[1 * 64 + p0 + 3];
+    const double d22 = Tc[2 * 64 + p0 + 2], d32 = Tc[2 * 64 + p0 + 3], d33 = Tc[3 * 64 + p0 + 3];
+    Chol4 c;
+    c.bad = !(d00 > 0.0);
+    c.r0 = rsqrt_f64(d00);
+    c.l10 = d10 * c.r0; c.l20 = d20 * c.r0; c.l30 = d30 * c.r0;
+    const double t11 = fma(-c.l10, c.l10, d11);
+    c.bad = c.bad || !(t11 > 0.0);
+    c.r1 = rsqrt_f64(t11);
+    c.l21 = fma(-c.l20, c.l10, d21) * c.r1;
+    c.l31 = fma(-c.l30, c.l10, d31) * c.r1;
+    const double t22 = fma(-c.l21, c.l21, fma(-c.l20, c.l20, d22));
+    c.bad = c.bad || !(t22 > 0.0);
+    c.r2 = rsqrt_f64(t22);
+    c.l32 = fma(-c.l31, c.l21, fma(-c.l30, c.l20, d32)) * c.r2;
+    const double t33 = fma(-c.l32, c.l32, fma(-c.l31, c.l31, fma(-c.l30, c.l30, d33)));
+    c.bad = c.bad || !(t33 > 0.0);
+    c.r3 = rsqrt_f64(t33);
+    return c;
 }
 
 __global__ void __launch_bounds__(256)
 chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-                 double* __restrict__ Linv, int32_t* __restrict__ status)
+                 double* __restrict__ Linv, int32_t* __restrict__ status, int pending)
 {
     if (step >= sel[slot_nblk]) return;
-    __shared__ double T[64 * CD_LD];        // A block -> L
-    __shared__ double M[64 * CD_LD];        // L^-1
-    __shared__ double G[4][16 * CD_LD];     // per-wave 16 x 16 scratch
-    const int t = threadIdx.x;
+    __shared__ double Lf[64 * CD_LD];       // L, column-major
+    __shared__ double Mf[64 * CD_LD];       // L^-1, column-major
+    __shared__ double Tcol[4 * 64];         // [k][row]: pivot columns of the trailing matrix
+    __shared__ double Mrow[4 * 64];         // [k][col]: pivot rows of the running inverse
+    __shared__ double Xs[4 * 64];           // [k][row]: panel, zero at and above the pivot rows
+    __shared__ double Ms[4 * 64];           // [k][col]: L4^-1 M(p,:), zero right of the pivot columns
+    const int t = threadIdx.x, l = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lr = l >> 4, lc = l & 15;
     double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
     double* Lout = Linv + (long)step * 64 * 64;
-    {
-        const int i = t & 63, g = t >> 6;
-        for (int q = 0; q < 16; ++q) {
-            const int c = g + 4 * q;     // the lower triangle is authoritative; mirror it
-            T[c * CD_LD + i] = (i >= c) ? tile[i + (long)c * ldA] : tile[c + (long)i * ldA];
-            M[c * CD_LD + i] = 0.0;
+    // lower-triangle 16 x 16 tiles in row-major order; wave w owns tiles w, w+4, w+8
+    constexpr int TR[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
+    constexpr int TC[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+    d4 accT[3], accM[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int idx = wave + 4 * o;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            double vT = 0.0, vM = 0.0;
+            if (idx < 10) {
+                const int row = 16 * TR[idx] + lr + 4 * reg, col = 16 * TC[idx] + lc;
+                // the lower triangle of the global tile is authoritative; mirror it
+                vT = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
+                vM = (row == col) ? 1.0 : 0.0;
+            }
+            accT[o][reg] = vT; accM[o][reg] = vM;
+        }
+    }
+    if (pending) {
+        // Lookahead: the trailing update of step-1 for THIS tile, A(k,k) -= X X^T with X = A(k,k-1)
+        // (already solved by panel(step-1)), is applied here so that the trailing-update kernel of
+        // the previous step can run on a second stream while this block is being factored.
+        const double* Xg = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
+        const int row = t & 63, g = t >> 6;
+        for (int qq = 0; qq < 16; ++qq) { const int c = g + 4 * qq; Lf[c * CD_LD + row] = Xg[row + (long)c * ldA]; }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int idx = wave + 4 * o;
+            if (idx < 10) {
+                const int tr = TR[idx], tc = TC[idx];
+#pragma unroll 4
+                for (int kk = 0; kk < 64; kk += 4)
+                    accT[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lf[(kk + lr) * CD_LD + 16 * tr + lc],
+                                                                   -Lf[(kk + lr) * CD_LD + 16 * tc + lc], accT[o], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    {   // pivot block 0: columns 0..3 of the (updated) block, rows 0..3 of the identity
+        const int row = t & 63, k = t >> 6;
+        Mrow[k * 64 + row] = (row == k) ? 1.0 : 0.0;
+        for (int c = k; c < 64; c += 4) { Lf[c * CD_LD + row] = 0.0; Mf[c * CD_LD + row] = 0.0; }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int idx = wave + 4 * o;
+            if (idx < 10 && TC[idx] == 0 && lc < 4) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Tcol[lc * 64 + 16 * TR[idx] + lr + 4 * reg] = accT[o][reg];
+            }
         }
     }
     __syncthreads();
     bool bad = false;
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
-        const int o = 16 * sb;
-        if (wave == 0) bad = factor16(T, M, o) || bad;
-        __syncthreads();
-        // sub-panel: T[a][sb] <- T[a][sb] * Li_sb^T for the sub-blocks below
-        const int a = sb + 1 + wave;
-        if (a < 4) {
-            const d4 acc = mm16_nt(T, 16 * a, o, M, o, o, zero);
-            st16(T, 16 * a, o, acc, 1.0, 0.0);       // the wave has read the whole block before it writes
-        }
-        __syncthreads();
-        // trailing: T[a][b] -= L[a][sb] * L[b][sb]^T for sb < b <= a
-        int idx = 0;
-        for (int ta = sb + 1; ta < 4; ++ta)
-            for (int tb = sb + 1; tb <= ta; ++tb, ++idx)
-                if ((idx & 3) == wave) {
-                    const d4 acc = mm16_nt(T, 16 * ta, o, T, 16 * tb, o, zero);
-                    st16(T, 16 * ta, 16 * tb, acc, -1.0, 1.0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p0 = 16 * sb + 4 * q;
+            // ---- A: 4 x 4 Cholesky of the pivot block (uniform, every lane)
+            const Chol4 c4 = chol4(Tcol, p0);
+            bad = bad || c4.bad;
+            // ---- B: panel row / inverse column by forward substitution
+            if (t < 128) {
+                const int e = t & 63;
+                const double* src = (t < 64) ? Tcol : Mrow;
+                const double a0 = src[e], a1 = src[64 + e], a2 = src[128 + e], a3 = src[192 + e];
+                const double x0 = a0 * c4.r0;
+                const double x1 = fma(-c4.l10, x0, a1) * c4.r1;
+                const double x2 = fma(-c4.l21, x1, fma(-c4.l20, x0, a2)) * c4.r2;
+                const double x3 = fma(-c4.l32, x2, fma(-c4.l31, x1, fma(-c4.l30, x0, a3))) * c4.r3;
+                if (t < 64) {
+                    // rows of the pivot block hold L4 itself (x_k is then l_{row,k}, and 1/r on the diagonal)
+                    const bool below = e > p0 + 3, inblk = e >= p0;
+                    Xs[e] = below ? x0 : 0.0; Xs[64 + e] = below ? x1 : 0.0;
+                    Xs[128 + e] = below ? x2 : 0.0; Xs[192 + e] = below ? x3 : 0.0;
+                    if (inblk) {
+                        const int d = e - p0;                         // >= 4 for rows below the block
+                        Lf[(p0 + 0) * CD_LD + e] = x0;
+                        if (d >= 1) Lf[(p0 + 1) * CD_LD + e] = x1;
+                        if (d >= 2) Lf[(p0 + 2) * CD_LD + e] = x2;
+                        if (d >= 3) Lf[(p0 + 3) * CD_LD + e] = x3;
+                    }
+                } else {
+                    // column e of rows p0..p0+3 of L^-1 (final); nothing right of the pivot columns
+                    const bool left = e <= p0 + 3;
+                    const double y0 = left ? x0 : 0.0, y1 = left ? x1 : 0.0, y2 = left ? x2 : 0.0, y3 = left ? x3 : 0.0;
+                    Ms[e] = y0; Ms[64 + e] = y1; Ms[128 + e] = y2; Ms[192 + e] = y3;
+                    if (left) {
+                        Mf[e * CD_LD + p0 + 0] = y0; Mf[e * CD_LD + p0 + 1] = y1;
+                        Mf[e * CD_LD + p0 + 2] = y2; Mf[e * CD_LD + p0 + 3] = y3;
+                    }
                 }
-        __syncthreads();
-    }
-    // off-diagonal blocks of L^-1 by block distance d: Linv[a][b] = -Li_aa * sum_{t=b}^{a-1} L[a][t] * Linv[t][b]
-    for (int dist = 1; dist < 4; ++dist) {
-        const int b = wave, a2 = wave + dist;
-        if (a2 < 4) {
-            d4 acc = zero;
-            for (int tt = b; tt < a2; ++tt) acc = mm16_nn(T, 16 * a2, 16 * tt, M, 16 * tt, 16 * b, acc);
-            st16(G[wave], 0, 0, acc, 1.0, 0.0);
+            }
+            __syncthreads();
+            // ---- C: rank-4 updates of the owned tiles, one MFMA each
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const int idx = wave + 4 * o;
+                if (idx < 10) {
+                    const int tr = TR[idx], tc = TC[idx];
+                    if (16 * tr + 15 > p0 + 3) {                       // some rows of the tile are below the pivot
+                        const double a = Xs[lr * 64 + 16 * tr + lc];
+                        if (16 * tc + 15 > p0 + 3)                     // trailing matrix: T -= X X^T
+                            accT[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Xs[lr * 64 + 16 * tc + lc], accT[o], 0, 0, 0);
+                        if (16 * tc <= p0 + 3)                         // inverse: M -= X (L4^-1 M(p,:))
+                            accM[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Ms[lr * 64 + 16 * tc + lc], accM[o], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- D: publish the next pivot block (columns p1..p1+3 of T, rows p1..p1+3 of M)
+            if (p0 + 4 < 64) {
+                const int p1 = p0 + 4, b1 = p1 >> 4, o1 = p1 & 15, q1 = (q + 1) & 3;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const int idx = wave + 4 * o;
+                    if (idx < 10) {
+                        const int tr = TR[idx], tc = TC[idx];
+                        if (tc == b1 && lc >= o1 && lc < o1 + 4) {
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) Tcol[(lc - o1) * 64 + 16 * tr + lr + 4 * reg] = accT[o][reg];
+                        }
+                        if (tr == b1) Mrow[lr * 64 + 16 * tc + lc] = accM[o][q1];   // rows o1 + lr of the tile = register q1
+                    }
+                }
+                if (q1 == 0 && wave == 0) {   // a new block row starts: columns right of its diagonal tile are still identity/zero
+                    for (int cc = 16 * (b1 + 1) + l; cc < 64; cc += 64) {
+                        Mrow[0 * 64 + cc] = 0.0; Mrow[1 * 64 + cc] = 0.0; Mrow[2 * 64 + cc] = 0.0; Mrow[3 * 64 + cc] = 0.0;
+                    }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (a2 < 4) {
-            const d4 acc = mm16_nn(M, 16 * a2, 16 * a2, G[wave], 0, 0, zero);
-            st16(M, 16 * a2, 16 * b, acc, -1.0, 0.0);
-        }
-        __syncthreads();
     }
     {
         const int i = t & 63, g = t >> 6;
-        for (int q = 0; q < 16; ++q) {
-            const int c = g + 4 * q;
-            Lout[i + 64 * c] = (i >= c) ? M[c * CD_LD + i] : 0.0;
-            if (i >= c) tile[i + (long)c * ldA] = T[c * CD_LD + i];
+        for (int qq = 0; qq < 16; ++qq) {
+            const int c = g + 4 * qq;
+            Lout[i + 64 * c] = (i >= c) ? Mf[c * CD_LD + i] : 0.0;
+            if (i >= c) tile[i + (long)c * ldA] = Lf[c * CD_LD + i];
         }
     }
-    if (bad && (t & 63) == 0) atomicMin(status, -6);        // RSLAM_ERR_NOT_SPD
+    if (bad && l == 0) atomicMin(status, -6);        // RSLAM_ERR_NOT_SPD
 }
 
 // rows of block b participate in step `step` of a sweep with nblk column blocks?
@@ -764,12 +800,13 @@ panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
 
 __global__ void __launch_bounds__(256)
 trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-             int rp_blocks)
+             int rp_blocks, int skip_next_diag)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int nblk = sel[slot_nblk];
     const int i = blockIdx.x, j = blockIdx.y + step + 1;
     if (step >= nblk || j >= nblk || i < j) return;
+    if (skip_next_diag && i == step + 1 && j == step + 1) return;   // applied by chol_diag_kernel(step+1) itself
     if (!row_block_active(i, step, nblk, rp_blocks)) return;
     const double* Ai = A + (long)i * 64 + (long)step * 64 * ldA;
     const double* Aj = A + (long)j * 64 + (long)step * 64 * ldA;
@@ -798,19 +835,36 @@ int init_kernel_attributes()
     return 0;
 }
 
-void launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_nblk, int cap_blocks,
-                         double* A, double* Linv, int32_t* status_sel)
+// Single stream: diag(k) panel(k) trail(k) per block step.
+// A two-stream lookahead variant (aux != nullptr: diag(k+1) applies the step-k update of its own
+// tile and trail(k) runs on a second stream, fork/join by events) is kept for measurement only:
+// on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the 7 us trailing
+// kernels they hide (C3 frame 0.68 ms against 0.52 ms single-stream, eager and hipGraph alike).
+void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
+                         const int32_t* sel, int slot_nblk, int cap_blocks, double* A, double* Linv,
+                         int32_t* status_sel)
 {
     const int rp_blocks = d.RP / 64;
     const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
     const int row_blocks = d.ldA / 64;
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
+    const bool two = (aux != nullptr && ev != nullptr);
     for (int step = 0; step < steps; ++step) {
-        chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, status_sel);
+        chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, status_sel, (two && step > 0) ? 1 : 0);
+        if (two && step > 0) (void)hipStreamWaitEvent(s, ev[2 * (step - 1) + 1], 0);      // trail(step-1) done
         panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
-        if (step + 1 < steps)
-            trail_kernel<<<dim3(row_blocks, steps - step - 1), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, rp_blocks);
+        if (step + 1 < steps) {
+            hipStream_t ts = s;
+            if (two) {
+                (void)hipEventRecord(ev[2 * step], s);
+                (void)hipStreamWaitEvent(aux, ev[2 * step], 0);
+                ts = aux;
+            }
+            trail_kernel<<<dim3(row_blocks, steps - step - 1), dim3(256), lds_bytes, ts>>>(A, d.ldA, step, sel, slot_nblk, rp_blocks, two ? 1 : 0);
+            if (two) (void)hipEventRecord(ev[2 * step + 1], aux);
+        }
     }
+    // the last trail(steps-2) was joined before panel(steps-1): nothing is left on aux
 }
 
 // ---------------------------------------------------------------------------

@@ -56,6 +56,8 @@ struct rslam_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;            // trailing updates of the factor sweep (lookahead)
+    std::vector<hipEvent_t> sweep_ev;            // fork/join events, 2 per block step
     // frame shape
     int n = 0, NP = 0, L = 0, m = 0, H = 0, words = 0, RP = 0, ldA = 0;
     int m_id = 0, m_euc = 0;
@@ -126,6 +128,7 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RSLAM_ERR_HIP; }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
     if (init_kernel_attributes() != 0 || init_kernel_attributes2() != 0) { (void)hipStreamDestroy(c->own_stream); delete c; return RSLAM_ERR_HIP; }
     bool ok = true;
     for (int i = 0; i < EV_COUNT; ++i) ok = ok && (hipEventCreate(&c->ev[i]) == hipSuccess);
@@ -154,6 +157,8 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RSLAM_OK;
@@ -367,7 +372,18 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     int32_t* sel = c->d_sel.p;
     launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p);
     if (ev_f0 >= 0) mark(c, ev_f0);
-    launch_factor_sweep(s, d, sel, slot_nblk, cap, c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
+    {
+        const size_t need = 2 * (size_t)(c->RP / 64 + 1);
+        while (c->sweep_ev.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+            c->sweep_ev.push_back(e);
+        }
+        static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // measured slower: off
+        const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
+        launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_nblk, cap,
+                            c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
+    }
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP > 0) {
         launch_state_update(s, d, sel, slot_k, slot_nblk, c->d_A.p, x_in, x_out, c->d_T.p, c->cfg.compat);
