@@ -575,6 +575,15 @@ constexpr int CD_LD = 65;
 
 struct Chol4 { double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3; bool bad; };
 
+#if defined(CD_STAMPS)   // diagnostic build: where do the cycles of a pivot step go (never in the product build)
+__device__ unsigned long long g_cd_stamps[8];
+#define CD_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define CD_ACC(slot, a, b) do { if (t == 0) g_cd_stamps[slot] += (b) - (a); } while (0)
+#else
+#define CD_STAMP(var)
+#define CD_ACC(slot, a, b)
+#endif
+
 __device__ __forceinline__ Chol4 chol4(const double* Tc /* [4][64] */, int p0)
 {
     const double d00 = Tc[0 * 64 + p0], d10 = Tc[0 * 64 + p0 + 1], d20 = Tc[0 * 64 + p0 + 2], d30 = Tc[0 * 64 + p0 + 3];
@@ -601,9 +610,13 @@ __device__ __forceinline__ Chol4 chol4(const double* Tc /* [4][64] */, int p0)
 
 __global__ void __launch_bounds__(256)
 chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-                 double* __restrict__ Linv, int32_t* __restrict__ status, int pending)
+                 int slot_k, double* __restrict__ Linv, int32_t* __restrict__ status, int pending)
 {
     if (step >= sel[slot_nblk]) return;
+    // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
+    // chain stops after the last real row, L and L^-1 are the identity there
+    const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
+    const int n_piv4 = (r_here + 3) >> 2;
     __shared__ double Lf[64 * CD_LD];       // L, column-major
     __shared__ double Mf[64 * CD_LD];       // L^-1, column-major
     __shared__ double Tcol[4 * 64];         // [k][row]: pivot columns of the trailing matrix
@@ -675,9 +688,13 @@ chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __re
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p0 = 16 * sb + 4 * q;
+            if (4 * sb + q >= n_piv4) break;             // uniform: only identity padding is left
             // ---- A: 4 x 4 Cholesky of the pivot block (uniform, every lane)
+            CD_STAMP(s0);
             const Chol4 c4 = chol4(Tcol, p0);
             bad = bad || c4.bad;
+            asm volatile("" :: "v"(c4.r3));
+            CD_STAMP(s1);
             // ---- B: panel row / inverse column by forward substitution
             if (t < 128) {
                 const int e = t & 63;
@@ -710,7 +727,9 @@ chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __re
                     }
                 }
             }
+            CD_STAMP(s2);
             __syncthreads();
+            CD_STAMP(s3);
             // ---- C: rank-4 updates of the owned tiles, one MFMA each
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
@@ -726,6 +745,7 @@ chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __re
                     }
                 }
             }
+            CD_STAMP(s4);
             // ---- D: publish the next pivot block (columns p1..p1+3 of T, rows p1..p1+3 of M)
             if (p0 + 4 < 64) {
                 const int p1 = p0 + 4, b1 = p1 >> 4, o1 = p1 & 15, q1 = (q + 1) & 3;
@@ -747,15 +767,23 @@ chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __re
                     }
                 }
             }
+            CD_STAMP(s5);
             __syncthreads();
+            CD_STAMP(s6);
+            CD_ACC(0, s0, s1); CD_ACC(1, s1, s2); CD_ACC(2, s2, s3); CD_ACC(3, s3, s4); CD_ACC(4, s4, s5); CD_ACC(5, s5, s6);
+            CD_ACC(6, s0, s6);
         }
     }
     {
         const int i = t & 63, g = t >> 6;
+        const int done = 4 * n_piv4;                 // pivots processed; beyond them L = L^-1 = I
         for (int qq = 0; qq < 16; ++qq) {
             const int c = g + 4 * qq;
-            Lout[i + 64 * c] = (i >= c) ? Mf[c * CD_LD + i] : 0.0;
-            if (i >= c) tile[i + (long)c * ldA] = Lf[c * CD_LD + i];
+            const bool pad = (c >= done);
+            const double lv = pad ? ((i == c) ? 1.0 : 0.0) : Lf[c * CD_LD + i];
+            const double mv = (i >= done) ? ((i == c) ? 1.0 : 0.0) : Mf[c * CD_LD + i];
+            Lout[i + 64 * c] = (i >= c) ? mv : 0.0;
+            if (i >= c) tile[i + (long)c * ldA] = lv;
         }
     }
     if (bad && l == 0) atomicMin(status, -6);        // RSLAM_ERR_NOT_SPD
@@ -824,6 +852,15 @@ trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     }
 }
 
+#if defined(CD_STAMPS)
+int debug_read_cd_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_stamps), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cd_stamps), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 int init_kernel_attributes()
 {
     const int bytes = (int)(sizeof(double) * TG_LDS_DOUBLES);
@@ -841,7 +878,7 @@ int init_kernel_attributes()
 // on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the 7 us trailing
 // kernels they hide (C3 frame 0.68 ms against 0.52 ms single-stream, eager and hipGraph alike).
 void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
-                         const int32_t* sel, int slot_nblk, int cap_blocks, double* A, double* Linv,
+                         const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Linv,
                          int32_t* status_sel)
 {
     const int rp_blocks = d.RP / 64;
@@ -850,7 +887,7 @@ void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * r
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
     const bool two = (aux != nullptr && ev != nullptr);
     for (int step = 0; step < steps; ++step) {
-        chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, status_sel, (two && step > 0) ? 1 : 0);
+        chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, slot_k, Linv, status_sel, (two && step > 0) ? 1 : 0);
         if (two && step > 0) (void)hipStreamWaitEvent(s, ev[2 * (step - 1) + 1], 0);      // trail(step-1) done
         panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
         if (step + 1 < steps) {
@@ -959,11 +996,13 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     double* Cs = lds;
     double* Ts = lds + TS_DOUBLES;
     tg_acc_to_lds(acc, Cs, 1.0);
+#pragma unroll 4
     for (int q = 0; q < 16; ++q) {                  // tile (bj,bi), element (row, c) -> Ts[c][row]
         const int c = g + 4 * q;
         Ts[c * TS_LD + row] = Pji[row + (long)c * ldp];
     }
     __syncthreads();
+#pragma unroll 4
     for (int q = 0; q < 16; ++q) {
         const int c = g + 4 * q;
         const double pij = Pij[row + (long)c * ldp];
@@ -974,6 +1013,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     }
     __syncthreads();
     if (bi != bj) {
+#pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             const int c = g + 4 * q;
             Cji[row + (long)c * ldo] = Cs[row * TS_LD + c];
@@ -981,7 +1021,6 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     }
 }
 
-int init_kernel_attributes2();
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo)
 {

@@ -381,7 +381,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         }
         static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // measured slower: off
         const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
-        launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_nblk, cap,
+        launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk, cap,
                             c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
     }
     if (ev_f1 >= 0) mark(c, ev_f1);
@@ -790,6 +790,16 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
     HIPCHK(hipMemcpy(d, p + 192, 512, hipMemcpyDeviceToHost));
     return RSLAM_OK;
 }
+
+#if defined(CD_STAMPS)
+namespace rslam { int debug_read_cd_stamps(unsigned long long* out, int reset); }
+extern "C" int rslam_debug_cd_stamps(rslam_ctx* c, unsigned long long* out, int reset)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return rslam::debug_read_cd_stamps(out, reset) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
+}
+#endif
 
 extern "C" int rslam_k_hbm_copy_peak(rslam_ctx* c, int64_t bytes, double* gbps)
 {

@@ -34,13 +34,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int TG_TILE = 64;     // output tile edge per workgroup
-constexpr int TG_KC = 32;       // K chunk staged per barrier
+#ifndef TG_KC_VALUE
+#define TG_KC_VALUE 32
+#endif
+constexpr int TG_KC = TG_KC_VALUE;       // K chunk staged per barrier
 constexpr int TG_LD = 80;       // LDS leading dimension (doubles)
 constexpr int TG_THREADS = 256;
 constexpr int TG_OPER_DOUBLES = TG_KC * TG_LD;              // one operand, one buffer
 constexpr int TG_LDS_DOUBLES = 4 * TG_OPER_DOUBLES;         // A,B x 2 buffers = 80 KiB
 
-struct TileRegs { d2 a[4]; d2 b[4]; };
+constexpr int TG_NQ = TG_KC / 8;   // 16-byte loads per thread, operand and chunk
+struct TileRegs { d2 a[TG_NQ]; d2 b[TG_NQ]; };
 
 // Each thread moves rows (2*rp, 2*rp+1) of columns cq + 8*q, q = 0..3.
 __device__ __forceinline__ void tg_load_chunk(const double* __restrict__ A, long lda,
@@ -50,7 +54,7 @@ __device__ __forceinline__ void tg_load_chunk(const double* __restrict__ A, long
     const int t = threadIdx.x;
     const int rp = t & 31, cq = t >> 5;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < TG_NQ; ++q) {
         const long c = k0 + cq + 8 * q;
         r.a[q] = *reinterpret_cast<const d2*>(A + 2 * rp + c * lda);
         r.b[q] = *reinterpret_cast<const d2*>(B + 2 * rp + c * ldb);
@@ -62,7 +66,7 @@ __device__ __forceinline__ void tg_store_chunk(double* As, double* Bs, const Til
     const int t = threadIdx.x;
     const int rp = t & 31, cq = t >> 5;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < TG_NQ; ++q) {
         const int c = cq + 8 * q;
         *reinterpret_cast<d2*>(As + c * TG_LD + 2 * rp) = r.a[q];
         *reinterpret_cast<d2*>(Bs + c * TG_LD + 2 * rp) = r.b[q];
@@ -126,7 +130,11 @@ __device__ __forceinline__ void tg_compute_chunk(const double* As, const double*
         double na0 = 0, na1 = 0;
         BFrag nb0 = {0, 0, 0, 0}, nb1 = {0, 0, 0, 0};
         if (kk + 4 < TG_KC) {
+#if defined(TG_EXP_NO_LDS_READ)
+            const int o = 0;
+#else
             const int o = (kk + 4) * TG_LD;
+#endif
             na0 = ap[o]; na1 = ap[o + 16];
             nb0.r0 = bp0[o]; nb0.r1 = bp1[o]; nb0.r2 = bp2[o]; nb0.r3 = bp3[o];
             nb1.r0 = bp0[o + 16]; nb1.r1 = bp1[o + 16]; nb1.r2 = bp2[o + 16]; nb1.r3 = bp3[o + 16];
@@ -158,7 +166,9 @@ __device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ A, long 
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const bool more = (c + 1 < nchunks);
+#if !defined(TG_EXP_NO_GLOBAL)
         if (more) tg_load_chunk(A, lda, B, ldb, (c + 1) * TG_KC, r);   // in flight under the MFMAs
+#endif
         if (c & 1) tg_compute_chunk(As1, Bs1, acc); else tg_compute_chunk(As0, Bs0, acc);
         if (more) { if (c & 1) tg_store_chunk(As0, Bs0, r); else tg_store_chunk(As1, Bs1, r); }
         __syncthreads();
@@ -177,6 +187,7 @@ __device__ __forceinline__ void tg_zero(d4 (&acc)[2][2])
 // epilogue can read columns (coalesced global stores) or rows (transposes).
 constexpr int TS_LD = 65;
 constexpr int TS_DOUBLES = 64 * TS_LD;
+static_assert(TG_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 tiles in the operand buffers");
 
 __device__ __forceinline__ void tg_acc_to_lds(const d4 (&acc)[2][2], double* Cs, double scale)
 {

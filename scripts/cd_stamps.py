@@ -1,0 +1,25 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ransac_slam_amd import default_config, api
+api.LIB_PATH = sys.argv[1]
+del api.SYMBOLS["rslam_k_mfma4_raw"]
+from ransac_slam_amd.synth import make_frame
+fr = make_frame(L=300, H=1000, seed=2)
+ctx = api.RslamHip(default_config(compat=1, adaptive=0))
+ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+L = api.lib()
+L.rslam_debug_cd_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+out = (C.c_ulonglong * 8)()
+for _ in range(3):
+    ctx.step_frame(False); ctx.sync()
+L.rslam_debug_cd_stamps(ctx._h, out, 1)
+N = 5
+for _ in range(N):
+    ctx.step_frame(False); ctx.sync()
+L.rslam_debug_cd_stamps(ctx._h, out, 1)
+v = np.array(list(out), dtype=float)
+steps = N * (1 + 7 * 16 + 13)      # LI: 1 pivot step; HI: 7 full blocks + 13 steps
+names = ["A chol4", "B subst", "wait->barrier1", "C mfma", "D publish", "barrier2", "total"]
+for n, x in zip(names, v[:7]):
+    print(f"{n:16s} {x / steps:9.1f} cycles per 4-pivot step  ({100 * x / max(v[6], 1):5.1f} %)")
