@@ -104,7 +104,8 @@ const char* rslam_version(void);
 
 /* Segment 1: replaces Tracking::search_IC_matches lines 35-44
  * (predict_camera_measurements, calculate_derivatives, S_i = H_i P H_i^T + R_i).
- * x_pred = x_k_km1 (n), P_pred = p_k_km1 (n*n, ld = n), both host.
+ * x_pred = x_k_km1 (n), P_pred = p_k_km1 (n*n, ld = n), both host; both NULL = use the
+ * prior that rslam_ekf_prediction left resident (layout may then be NULL too).
  * Outputs (host): h (L*2, row i = feature i), visible (L), S (L*4, 2x2 col-major).
  * For features that are not visible h and S entries are left untouched. */
 int rslam_predict(rslam_ctx* ctx, const rslam_layout* layout,
@@ -124,6 +125,17 @@ int rslam_ransac_update(rslam_ctx* ctx, const double* z, const uint8_t* ic,
                         uint8_t* li, uint8_t* hi,
                         int32_t* best_hyp, int32_t* best_support,
                         int32_t* hyps_evaluated);
+
+/* EKF prediction on the device (the step just before the hot path):
+ * replaces ExtendKF::ekf_prediction (src/ExtendKF.cpp:333-388) for the "constant_velocity"
+ * filter the reference instantiates (src/System.cpp:63).  It turns the resident posterior --
+ * left by rslam_ransac_update, or uploaded with rslam_set_posterior after Map::map_management
+ * edited x_k_k / p_k_k on the host -- into the resident prior x_k_km1 / p_k_km1; a following
+ * rslam_predict(ctx, layout, NULL, NULL, ...) then runs without any upload.  delta_t = 1 and
+ * std_a = Sigma.a, std_alpha = Sigma.alpha in the reference (ExtendKF.cpp:336,347-348). */
+int rslam_set_posterior (rslam_ctx* ctx, const rslam_layout* layout, const double* x_kk, const double* P_kk);
+int rslam_ekf_prediction(rslam_ctx* ctx, double delta_t, double std_a, double std_alpha);
+int rslam_fetch_prior   (rslam_ctx* ctx, double* x_pred /* host n, may be NULL */, double* P_pred /* host n*n, may be NULL */);
 
 int rslam_fetch_cov  (rslam_ctx* ctx, double* P /* host, n*n */);
 int rslam_fetch_state(rslam_ctx* ctx, double* x /* host, n   */);

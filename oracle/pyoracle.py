@@ -63,6 +63,8 @@ def lib():
         L.orc_adaptive_n_hyp.argtypes = [C.c_double, C.c_int, C.c_int]
         L.orc_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.orc_inverse_lu.argtypes = [C.c_int, _dp, _dp]
+        L.orc_ekf_prediction.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.orc_motion_model.argtypes = [_dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -252,3 +254,24 @@ def inverse_lu(A):
     out = np.zeros((n, n), order="F")
     lib().orc_inverse_lu(n, _p(A), _p(out))
     return out
+
+
+def ekf_prediction(x_kk, P_kk, delta_t=1.0, std_a=0.007, std_alpha=0.007):
+    x = np.ascontiguousarray(x_kk, np.float64)
+    P = np.asfortranarray(P_kk, np.float64)
+    n = len(x)
+    xo = np.zeros(n)
+    Po = np.zeros((n, n), order="F")
+    rc = lib().orc_ekf_prediction(n, _p(x), _p(P), delta_t, std_a, std_alpha, _p(xo), _p(Po))
+    if rc:
+        raise OracleError(rc)
+    return xo, Po
+
+
+def motion_model(xv, delta_t=1.0, std_a=0.007, std_alpha=0.007):
+    xv = np.ascontiguousarray(xv, np.float64)
+    xp = np.zeros(13)
+    F = np.zeros((13, 13), order="F")
+    Q = np.zeros((13, 13), order="F")
+    lib().orc_motion_model(_p(xv), delta_t, std_a, std_alpha, _p(xp), _p(F), _p(Q))
+    return xp, F, Q

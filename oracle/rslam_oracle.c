@@ -1016,6 +1016,155 @@ int orc_ransac_update(orc_ctx* c, const double* z, const uint8_t* ic, const doub
 }
 
 /* ------------------------------------------------------------------ */
+/* EKF prediction (the step just before the hot path)  */
+/* ------------------------------------------------------------------ */
+
+/* ExtendKF::v2q, ExtendKF.cpp:428-443 (eps = DBL_EPSILON, :24) */
+static void v2q(const double v[3], double q[4])
+{
+    const double theta = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (theta < DBL_EPSILON) { q[0] = q[1] = q[2] = q[3] = 0; return; }
+    double vn[3] = { v[0] / theta, v[1] / theta, v[2] / theta };
+    const double nn = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+    q[0] = cos(theta / 2.0);
+    for (int a = 0; a < 3; ++a) q[1 + a] = sin(theta / 2.0) * (vn[a] / nn);
+}
+
+/* ExtendKF::qprod, ExtendKF.cpp:416-427 */
+static void qprod(const double q[4], const double wW[3], double delta_t, double qp[4])
+{
+    double v[3] = { wW[0] * delta_t, wW[1] * delta_t, wW[2] * delta_t }, p[4];
+    v2q(v, p);
+    const double* qv = q + 1; const double* pu = p + 1;
+    const double cx = qv[1] * pu[2] - qv[2] * pu[1];
+    const double cy = qv[2] * pu[0] - qv[0] * pu[2];
+    const double cz = qv[0] * pu[1] - qv[1] * pu[0];
+    qp[0] = q[0] * p[0] - (qv[0] * pu[0] + qv[1] * pu[1] + qv[2] * pu[2]);
+    qp[1] = (q[0] * pu[0] + p[0] * qv[0]) + cx;
+    qp[2] = (q[0] * pu[1] + p[0] * qv[1]) + cy;
+    qp[3] = (q[0] * pu[2] + p[0] * qv[2]) + cz;
+}
+
+/* ExtendKF.cpp:513-529 */
+static double dq0_by_domegaA(double omegaA, double omega, double delta_t)
+{ return (-delta_t / 2.0) * (omegaA / omega) * sin(omega * delta_t / 2.0); }
+static double dqA_by_domegaA(double omegaA, double omega, double delta_t)
+{
+    return (delta_t / 2.0) * omegaA * omegaA / (omega * omega) * cos(omega * delta_t / 2.0)
+         + (1.0 / omega) * (1.0 - omegaA * omegaA / (omega * omega)) * sin(omega * delta_t / 2.0);
+}
+static double dqA_by_domegaB(double omegaA, double omegaB, double omega, double delta_t)
+{
+    return (omegaA * omegaB / (omega * omega)) *
+           ((delta_t / 2.0) * cos(omega * delta_t / 2.0) - (1.0 / omega) * sin(omega * delta_t / 2.0));
+}
+/* ExtendKF::dqomegadt_by_domega, ExtendKF.cpp:491-512; out 4x3 col-major */
+static void dqomegadt_by_domega(const double w[3], double dt, double out[12])
+{
+    const double m = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+#define O(i, j) out[(i) + 4 * (j)]
+    O(0,0) = dq0_by_domegaA(w[0], m, dt); O(0,1) = dq0_by_domegaA(w[1], m, dt); O(0,2) = dq0_by_domegaA(w[2], m, dt);
+    O(1,0) = dqA_by_domegaA(w[0], m, dt); O(1,1) = dqA_by_domegaB(w[0], w[1], m, dt); O(1,2) = dqA_by_domegaB(w[0], w[2], m, dt);
+    O(2,0) = dqA_by_domegaB(w[1], w[0], m, dt); O(2,1) = dqA_by_domegaA(w[1], m, dt); O(2,2) = dqA_by_domegaB(w[1], w[2], m, dt);
+    O(3,0) = dqA_by_domegaB(w[2], w[0], m, dt); O(3,1) = dqA_by_domegaB(w[2], w[1], m, dt); O(3,2) = dqA_by_domegaA(w[2], m, dt);
+#undef O
+}
+/* ExtendKF::dq3_by_dq1, ExtendKF.cpp:482-490; out 4x4 col-major */
+static void dq3_by_dq1(const double q[4], double out[16])
+{
+    const double r[16] = { q[0], -q[1], -q[2], -q[3],
+                           q[1],  q[0], -q[3],  q[2],
+                           q[2],  q[3],  q[0], -q[1],
+                           q[3], -q[2],  q[1],  q[0] };
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i + 4 * j] = r[4 * i + j];
+}
+
+/* The 13-state motion model of ExtendKF::ekf_prediction for filter_type
+ * "constant_velocity" (the only one the reference instantiates, System.cpp:63):
+ * fv (ExtendKF.cpp:389-400), dfv_by_dxv (:444-465), Q = G Pn G' (:347-376).
+ * F, Q are 13x13 col-major. */
+void orc_motion_model(const double xv[13], double delta_t, double std_a, double std_alpha,
+                      double xv_pred[13], double F[169], double Q[169])
+{
+    const double* rW = xv; const double* qWR = xv + 3; const double* vW = xv + 7; const double* wW = xv + 10;
+    for (int a = 0; a < 3; ++a) xv_pred[a] = rW[a] + vW[a] * delta_t;
+    qprod(qWR, wW, delta_t, xv_pred + 3);
+    for (int a = 0; a < 3; ++a) { xv_pred[7 + a] = vW[a]; xv_pred[10 + a] = wW[a]; }
+
+    memset(F, 0, sizeof(double) * 169);
+    for (int i = 0; i < 13; ++i) F[i + 13 * i] = 1.0;
+    double wt[3] = { wW[0] * delta_t, wW[1] * delta_t, wW[2] * delta_t }, qwt[4];
+    v2q(wt, qwt);
+    const double blk[16] = { qwt[0], -qwt[1], -qwt[2], -qwt[3],
+                             qwt[1],  qwt[0],  qwt[3], -qwt[2],
+                             qwt[2], -qwt[3],  qwt[0],  qwt[1],
+                             qwt[3],  qwt[2], -qwt[1],  qwt[0] };
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) F[(3 + i) + 13 * (3 + j)] = blk[4 * i + j];
+    for (int a = 0; a < 3; ++a) F[a + 13 * (7 + a)] = delta_t;
+    double a44[16], b43[12], ab[12];
+    dq3_by_dq1(qWR, a44);
+    dqomegadt_by_domega(wW, delta_t, b43);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double sacc = 0;
+            for (int k = 0; k < 4; ++k) sacc += a44[i + 4 * k] * b43[k + 4 * j];
+            ab[i + 4 * j] = sacc;
+            F[(3 + i) + 13 * (10 + j)] = sacc;
+        }
+    /* Q = G * Pn * G' */
+    const double la = pow(std_a * delta_t, 2), aa = pow(std_alpha * delta_t, 2);
+    const double Pn[6] = { la, la, la, aa, aa, aa };
+    double G[13 * 6];
+    memset(G, 0, sizeof(G));
+    for (int a = 0; a < 3; ++a) { G[(7 + a) + 13 * a] = 1.0; G[(10 + a) + 13 * (3 + a)] = 1.0; G[a + 13 * a] = delta_t; }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) G[(3 + i) + 13 * (3 + j)] = ab[i + 4 * j];
+    for (int i = 0; i < 13; ++i)
+        for (int j = 0; j < 13; ++j) {
+            double sacc = 0;
+            for (int k = 0; k < 6; ++k) sacc += (G[i + 13 * k] * Pn[k]) * G[j + 13 * k];
+            Q[i + 13 * j] = sacc;
+        }
+}
+
+/* ExtendKF::ekf_prediction, ExtendKF.cpp:333-388.  x_kk (n), P_kk (n x n) -> x_pred, P_pred. */
+int orc_ekf_prediction(int n, const double* x_kk, const double* P_kk, double delta_t, double std_a,
+                       double std_alpha, double* x_pred, double* P_pred)
+{
+    if (n < 13 || !x_kk || !P_kk || !x_pred || !P_pred) return RSLAM_ERR_ARG;
+    double F[169], Q[169], xv[13];
+    orc_motion_model(x_kk, delta_t, std_a, std_alpha, xv, F, Q);
+    memcpy(x_pred, x_kk, sizeof(double) * n);
+    memcpy(x_pred, xv, sizeof(double) * 13);
+    memcpy(P_pred, P_kk, sizeof(double) * (size_t)n * n);                 /* pk_km5 = bottom-right block */
+    double FP[169];
+    for (int i = 0; i < 13; ++i)                                            /* pk_km2 = F*P11*F' + Q */
+        for (int j = 0; j < 13; ++j) {
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) sacc += F[i + 13 * k] * P_kk[k + (size_t)j * n];
+            FP[i + 13 * j] = sacc;
+        }
+    for (int i = 0; i < 13; ++i)
+        for (int j = 0; j < 13; ++j) {
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) sacc += FP[i + 13 * k] * F[j + 13 * k];
+            P_pred[i + (size_t)j * n] = sacc + Q[i + 13 * j];
+        }
+    for (int j = 13; j < n; ++j)                                            /* pk_km3 = F * P12 */
+        for (int i = 0; i < 13; ++i) {
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) sacc += F[i + 13 * k] * P_kk[k + (size_t)j * n];
+            P_pred[i + (size_t)j * n] = sacc;
+        }
+    for (int i = 13; i < n; ++i)                                            /* pk_km4 = P21 * F' */
+        for (int j = 0; j < 13; ++j) {
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) sacc += P_kk[i + (size_t)k * n] * F[j + 13 * k];
+            P_pred[i + (size_t)j * n] = sacc;
+        }
+    return RSLAM_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* introspection                                                        */
 /* ------------------------------------------------------------------ */
 

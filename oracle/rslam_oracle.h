@@ -84,6 +84,12 @@ int  orc_adaptive_n_hyp(double p, int support, int num_ic);
 int  orc_update(int compat, int n, int r, const double* x, const double* P,
                 const double* H, const double* z, const double* h,
                 double* x_out, double* P_out);
+/* ExtendKF::ekf_prediction (ExtendKF.cpp:333-388), "constant_velocity" filter (System.cpp:63) */
+int  orc_ekf_prediction(int n, const double* x_kk, const double* P_kk, double delta_t, double std_a,
+                        double std_alpha, double* x_pred, double* P_pred);
+/* its 13-state motion model: fv (:389-400), dfv_by_dxv (:444-465), Q = G Pn G' (:347-376) */
+void orc_motion_model(const double xv[13], double delta_t, double std_a, double std_alpha,
+                      double xv_pred[13], double F[169], double Q[169]);
 /* dynamic-size inverse as Eigen does it (PartialPivLU), Tracking.cpp:421 */
 int  orc_inverse_lu(int n, const double* A, double* Ainv);
 

@@ -28,6 +28,9 @@ SYMBOLS = {
     "rslam_version": (C.c_char_p, []),
     "rslam_predict": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp, _dp, _u8p, _dp]),
     "rslam_ransac_update": (C.c_int, [C.c_void_p, _dp, _u8p, _dp, C.c_int32, _dp, _dp, _u8p, _u8p, _i32p, _i32p, _i32p]),
+    "rslam_set_posterior": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp]),
+    "rslam_ekf_prediction": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "rslam_fetch_prior": (C.c_int, [C.c_void_p, _dp, _dp]),
     "rslam_fetch_cov": (C.c_int, [C.c_void_p, _dp]),
     "rslam_fetch_state": (C.c_int, [C.c_void_p, _dp]),
     "rslam_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -119,6 +122,31 @@ class RslamHip:
         S = np.full((self.L, 4), np.nan)
         _chk(lib().rslam_predict(self._h, C.byref(lay), _p(x), _p(P), _p(h), _p(vis, _u8p), _p(S)), "rslam_predict")
         return h, vis, S
+
+    def predict_resident(self):
+        """Segment 1 on the prior that ekf_prediction() left in HBM (no upload)."""
+        h = np.full((self.L, 2), np.nan)
+        vis = np.zeros(self.L, np.uint8)
+        S = np.full((self.L, 4), np.nan)
+        _chk(lib().rslam_predict(self._h, None, None, None, _p(h), _p(vis, _u8p), _p(S)), "rslam_predict")
+        return h, vis, S
+
+    def set_posterior(self, types, x_kk, P_kk):
+        lay, keep = make_layout(types)
+        self._keep = keep
+        self.n, self.L = lay.n, lay.L
+        x = np.ascontiguousarray(x_kk, dtype=np.float64)
+        P = np.asfortranarray(P_kk, dtype=np.float64)
+        _chk(lib().rslam_set_posterior(self._h, C.byref(lay), _p(x), _p(P)), "rslam_set_posterior")
+
+    def ekf_prediction(self, delta_t=1.0, std_a=0.007, std_alpha=0.007):
+        _chk(lib().rslam_ekf_prediction(self._h, delta_t, std_a, std_alpha), "rslam_ekf_prediction")
+
+    def fetch_prior(self):
+        x = np.zeros(self.n)
+        P = np.zeros((self.n, self.n), order="F")
+        _chk(lib().rslam_fetch_prior(self._h, _p(x), _p(P)), "rslam_fetch_prior")
+        return x, P
 
     def ransac_update(self, z, ic, draws, want_P=True):
         z = np.ascontiguousarray(z, dtype=np.float64)

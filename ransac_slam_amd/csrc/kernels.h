@@ -78,6 +78,10 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo);
 void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_k, const double* T, double* P);
 
+// x_pred[0:13], FQ (338 doubles) and the 13-row/column strips of P_pred; the caller copies
+// x[13:] and P beforehand
+void launch_ekf_prediction(hipStream_t s, int n, int NP, const double* x_kk, const double* P_kk, double dt,
+                           double std_a, double std_alpha, double* x_pred, double* P_pred, double* FQ);
 int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kernels (80 KiB)
 int init_kernel_attributes2();
 void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,

@@ -1078,6 +1078,129 @@ void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_
 }
 
 // ---------------------------------------------------------------------------
+// EKF prediction, ExtendKF::ekf_prediction, ExtendKF.cpp:333-388, for the
+// "constant_velocity" filter the reference instantiates (System.cpp:63).  The 13-state motion
+// model (fv :389-400, dfv_by_dxv :444-465, Q = G Pn G' :347-376) is one lane's work; the
+// covariance only changes in its first 13 rows/columns (:379-387): a strip kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void v2q_dev(const double v[3], double q[4])
+{
+    const double theta = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (theta < 2.220446049250313e-16) { q[0] = q[1] = q[2] = q[3] = 0; return; }     // eps, ExtendKF.cpp:24,436
+    const double vn[3] = { v[0] / theta, v[1] / theta, v[2] / theta };
+    const double nn = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+    double sh, ch;
+    sincos(theta / 2.0, &sh, &ch);
+    q[0] = ch;
+    for (int a = 0; a < 3; ++a) q[1 + a] = sh * (vn[a] / nn);
+}
+
+__global__ void ekf_motion_kernel(const double* __restrict__ x_kk, double dt, double std_a, double std_alpha,
+                                  double* __restrict__ x_pred, double* __restrict__ FQ)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double* F = FQ; double* Q = FQ + 169;
+    const double* rW = x_kk; const double* q = x_kk + 3; const double* vW = x_kk + 7; const double* wW = x_kk + 10;
+    for (int a = 0; a < 3; ++a) x_pred[a] = rW[a] + vW[a] * dt;
+    {   // qprod, ExtendKF.cpp:416-427
+        const double v[3] = { wW[0] * dt, wW[1] * dt, wW[2] * dt };
+        double p[4];
+        v2q_dev(v, p);
+        const double* qv = q + 1; const double* pu = p + 1;
+        x_pred[3] = q[0] * p[0] - (qv[0] * pu[0] + qv[1] * pu[1] + qv[2] * pu[2]);
+        x_pred[4] = (q[0] * pu[0] + p[0] * qv[0]) + (qv[1] * pu[2] - qv[2] * pu[1]);
+        x_pred[5] = (q[0] * pu[1] + p[0] * qv[1]) + (qv[2] * pu[0] - qv[0] * pu[2]);
+        x_pred[6] = (q[0] * pu[2] + p[0] * qv[2]) + (qv[0] * pu[1] - qv[1] * pu[0]);
+    }
+    for (int a = 0; a < 3; ++a) { x_pred[7 + a] = vW[a]; x_pred[10 + a] = wW[a]; }
+    for (int k = 0; k < 169; ++k) { F[k] = 0.0; Q[k] = 0.0; }
+    for (int i = 0; i < 13; ++i) F[i + 13 * i] = 1.0;
+    {
+        const double wt[3] = { wW[0] * dt, wW[1] * dt, wW[2] * dt };
+        double qw[4];
+        v2q_dev(wt, qw);
+        const double blk[16] = { qw[0], -qw[1], -qw[2], -qw[3],  qw[1], qw[0], qw[3], -qw[2],
+                                 qw[2], -qw[3], qw[0], qw[1],    qw[3], qw[2], -qw[1], qw[0] };
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) F[(3 + i) + 13 * (3 + j)] = blk[4 * i + j];
+    }
+    for (int a = 0; a < 3; ++a) F[a + 13 * (7 + a)] = dt;
+    // dq3_by_dq1(qOld) * dqomegadt_by_domega(omegaOld, dt), ExtendKF.cpp:463-465,482-529
+    double ab[12];
+    {
+        const double a44[16] = { q[0], -q[1], -q[2], -q[3],  q[1], q[0], -q[3], q[2],
+                                 q[2], q[3], q[0], -q[1],    q[3], -q[2], q[1], q[0] };      // row-major
+        const double m = sqrt(wW[0] * wW[0] + wW[1] * wW[1] + wW[2] * wW[2]);
+        double sh, ch;
+        sincos(m * dt / 2.0, &sh, &ch);
+        double b43[12];                                                                     // [i][j] row-major 4x3
+        for (int j = 0; j < 3; ++j) b43[j] = (-dt / 2.0) * (wW[j] / m) * sh;
+        for (int a = 0; a < 3; ++a)
+            for (int j = 0; j < 3; ++j)
+                b43[3 * (1 + a) + j] = (a == j)
+                    ? (dt / 2.0) * wW[a] * wW[a] / (m * m) * ch + (1.0 / m) * (1.0 - wW[a] * wW[a] / (m * m)) * sh
+                    : (wW[a] * wW[j] / (m * m)) * ((dt / 2.0) * ch - (1.0 / m) * sh);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double sacc = 0;
+                for (int k = 0; k < 4; ++k) sacc += a44[4 * i + k] * b43[3 * k + j];
+                ab[i + 4 * j] = sacc;
+                F[(3 + i) + 13 * (10 + j)] = sacc;
+            }
+    }
+    {   // Q = G Pn G'
+        const double la = (std_a * dt) * (std_a * dt), aa = (std_alpha * dt) * (std_alpha * dt);
+        double G[13 * 6];
+        for (int k = 0; k < 78; ++k) G[k] = 0.0;
+        for (int a = 0; a < 3; ++a) { G[(7 + a) + 13 * a] = 1.0; G[(10 + a) + 13 * (3 + a)] = 1.0; G[a + 13 * a] = dt; }
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) G[(3 + i) + 13 * (3 + j)] = ab[i + 4 * j];
+        for (int i = 0; i < 13; ++i)
+            for (int j = 0; j < 13; ++j) {
+                double sacc = 0;
+                for (int k = 0; k < 6; ++k) sacc += (G[i + 13 * k] * (k < 3 ? la : aa)) * G[j + 13 * k];
+                Q[i + 13 * j] = sacc;
+            }
+    }
+}
+
+// Pout must already hold a copy of P (the bottom-right block pk_km5 is unchanged).
+__global__ void __launch_bounds__(256)
+ekf_cov_kernel(int n, int NP, const double* __restrict__ P, const double* __restrict__ FQ, double* __restrict__ Pout)
+{
+    __shared__ double F[169], Q[169];
+    for (int k = threadIdx.x; k < 169; k += 256) { F[k] = FQ[k]; Q[k] = FQ[169 + k]; }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    if (j >= 13) {
+        double col[13], rowv[13];
+        for (int k = 0; k < 13; ++k) { col[k] = P[k + (long)j * NP]; rowv[k] = P[j + (long)k * NP]; }
+        for (int i = 0; i < 13; ++i) {
+            double s1 = 0, s2 = 0;
+            for (int k = 0; k < 13; ++k) { s1 += F[i + 13 * k] * col[k]; s2 += rowv[k] * F[i + 13 * k]; }
+            Pout[i + (long)j * NP] = s1;            // pk_km3 = F * P12
+            Pout[j + (long)i * NP] = s2;            // pk_km4 = P21 * F'
+        }
+    } else {                                        // column j of pk_km2 = (F * P11) * F' + Q
+        for (int i = 0; i < 13; ++i) {
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) {
+                double fp = 0;                      // (F * P11)(i, k)
+                for (int mm = 0; mm < 13; ++mm) fp += F[i + 13 * mm] * P[mm + (long)k * NP];
+                sacc += fp * F[j + 13 * k];
+            }
+            Pout[i + (long)j * NP] = sacc + Q[i + 13 * j];
+        }
+    }
+}
+
+void launch_ekf_prediction(hipStream_t s, int n, int NP, const double* x_kk, const double* P_kk, double dt,
+                           double std_a, double std_alpha, double* x_pred, double* P_pred, double* FQ)
+{
+    ekf_motion_kernel<<<dim3(1), dim3(64), 0, s>>>(x_kk, dt, std_a, std_alpha, x_pred, FQ);
+    ekf_cov_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(n, NP, P_kk, FQ, P_pred);
+}
+
+// ---------------------------------------------------------------------------
 // Generic dense NT GEMM on the same MFMA tile engine (dense form of P*H^T).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

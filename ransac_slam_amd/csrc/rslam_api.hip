@@ -62,6 +62,7 @@ struct rslam_ctx {
     int n = 0, NP = 0, L = 0, m = 0, H = 0, words = 0, RP = 0, ldA = 0;
     int m_id = 0, m_euc = 0;
     bool have_state = false, have_meas = false, predicted = false, pht_done = false, dedup_done = false;
+    bool have_post = false;      // (d_x2, d_P) hold a posterior x_k_k / p_k_k
     std::vector<uint8_t> h_type, h_vis;
     std::vector<int32_t> h_off;
     // device buffers
@@ -70,7 +71,7 @@ struct rslam_ctx {
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Linv,
-                   d_x1, d_x2, d_P, d_T, d_probe;
+                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ;
     // timing
     int timing = 0;
     hipEvent_t ev[EV_COUNT];
@@ -155,7 +156,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_xpred.release(); c->d_Ppred.release(); c->d_h.release(); c->d_h2.release(); c->d_H13.release();
     c->d_H13b.release(); c->d_S.release(); c->d_S2.release(); c->d_z.release(); c->d_wv.release();
     c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
-    c->d_P.release(); c->d_T.release(); c->d_probe.release();
+    c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -182,10 +183,10 @@ extern "C" int rslam_enable_timing(rslam_ctx* c, int on)
 // ------------------------------------------------------------------------
 // uploads
 // ------------------------------------------------------------------------
-static int upload_state(rslam_ctx* c, const rslam_layout* lay, const double* x_pred, const double* P_pred)
+// validate a layout, size the per-frame buffers, upload the layout tables
+static int set_layout(rslam_ctx* c, const rslam_layout* lay)
 {
-    if (!lay || !x_pred || !P_pred || lay->n < 13 || lay->L < 0 || (lay->L > 0 && (!lay->type || !lay->offset)))
-        return RSLAM_ERR_ARG;
+    if (!lay || lay->n < 13 || lay->L < 0 || (lay->L > 0 && (!lay->type || !lay->offset))) return RSLAM_ERR_ARG;
     const int n = lay->n, L = lay->L;
     for (int i = 0; i < L; ++i) {
         if (lay->type[i] > 1) return RSLAM_ERR_ARG;
@@ -203,22 +204,39 @@ static int upload_state(rslam_ctx* c, const rslam_layout* lay, const double* x_p
 #define ENS(buf, cnt) do { r = (buf).ensure(cnt); if (r < 0) return RSLAM_ERR_HIP; re |= r; } while (0)
     ENS(c->d_type, L); ENS(c->d_off, L); ENS(c->d_vis, L); ENS(c->d_hash, L); ENS(c->d_hash2, L);
     ENS(c->d_ic, L); ENS(c->d_li, L); ENS(c->d_hi, L); ENS(c->d_rank_of, L);
-    ENS(c->d_xpred, NP); ENS(c->d_x1, NP); ENS(c->d_x2, NP);
+    ENS(c->d_xpred, NP); ENS(c->d_x1, NP); ENS(c->d_x2, NP); ENS(c->d_FQ, 338);
     ENS(c->d_Ppred, (size_t)NP * NP); ENS(c->d_P, (size_t)NP * NP);
     ENS(c->d_h, 2 * (size_t)L); ENS(c->d_h2, 2 * (size_t)L); ENS(c->d_H13, 26 * (size_t)L); ENS(c->d_H13b, 26 * (size_t)L);
     ENS(c->d_S, 4 * (size_t)L); ENS(c->d_S2, 4 * (size_t)L); ENS(c->d_z, 2 * (size_t)L);
-    if (re) invalidate_graph(c);
+    if (re) { invalidate_graph(c); c->have_post = false; c->have_state = false; }
     hipStream_t s = c->stream;
     if (L > 0) {
         HIPCHK(hipMemcpyAsync(c->d_type.p, lay->type, L, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->d_off.p, lay->offset, sizeof(int32_t) * L, hipMemcpyHostToDevice, s));
     }
-    HIPCHK(hipMemsetAsync(c->d_xpred.p, 0, sizeof(double) * NP, s));
-    HIPCHK(hipMemcpyAsync(c->d_xpred.p, x_pred, sizeof(double) * n, hipMemcpyHostToDevice, s));
-    if (NP != n) HIPCHK(hipMemsetAsync(c->d_Ppred.p, 0, sizeof(double) * (size_t)NP * NP, s));
-    HIPCHK(hipMemcpy2DAsync(c->d_Ppred.p, sizeof(double) * NP, P_pred, sizeof(double) * n, sizeof(double) * n, n,
-                            hipMemcpyHostToDevice, s));
+    return RSLAM_OK;
+}
+
+// host (x, P) -> padded device buffers
+static int upload_xp(rslam_ctx* c, const double* x, const double* P, double* d_x, double* d_Pm)
+{
+    hipStream_t s = c->stream;
+    const int n = c->n, NP = c->NP;
+    HIPCHK(hipMemsetAsync(d_x, 0, sizeof(double) * NP, s));
+    HIPCHK(hipMemcpyAsync(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    if (NP != n) HIPCHK(hipMemsetAsync(d_Pm, 0, sizeof(double) * (size_t)NP * NP, s));
+    HIPCHK(hipMemcpy2DAsync(d_Pm, sizeof(double) * NP, P, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
+    return RSLAM_OK;
+}
+
+static int upload_state(rslam_ctx* c, const rslam_layout* lay, const double* x_pred, const double* P_pred)
+{
+    if (!x_pred || !P_pred) return RSLAM_ERR_ARG;
+    int rc = set_layout(c, lay);
+    if (rc) return rc;
+    rc = upload_xp(c, x_pred, P_pred, c->d_xpred.p, c->d_Ppred.p);
+    if (rc) return rc;
     c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false;
     return RSLAM_OK;
 }
@@ -440,6 +458,7 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);
+    c->have_post = true;
     return RSLAM_OK;
 }
 
@@ -510,8 +529,16 @@ extern "C" int rslam_predict(rslam_ctx* c, const rslam_layout* layout, const dou
                              double* h, uint8_t* visible, double* S)
 {
     if (!c) return RSLAM_ERR_ARG;
-    int rc = upload_state(c, layout, x_pred, P_pred);
-    if (rc) return rc;
+    int rc;
+    if (!x_pred && !P_pred) {                      // prior left resident by rslam_ekf_prediction
+        if (!c->have_state) return RSLAM_ERR_STATE;
+        if (layout && (layout->n != c->n || layout->L != c->L)) return RSLAM_ERR_ARG;
+        HIPCHK(hipSetDevice(c->device));
+        c->have_meas = false;
+    } else {
+        rc = upload_state(c, layout, x_pred, P_pred);
+        if (rc) return rc;
+    }
     rc = enqueue_predict(c);
     if (rc) return rc;
     const int L = c->L;
@@ -528,6 +555,47 @@ extern "C" int rslam_predict(rslam_ctx* c, const rslam_layout* layout, const dou
         if (h) { h[2 * i] = hh[2 * i]; h[2 * i + 1] = hh[2 * i + 1]; }
         if (S) memcpy(S + 4 * i, SS.data() + 4 * i, sizeof(double) * 4);
     }
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// EKF prediction on the resident posterior
+// ------------------------------------------------------------------------
+extern "C" int rslam_set_posterior(rslam_ctx* c, const rslam_layout* layout, const double* x_kk, const double* P_kk)
+{
+    if (!c || !x_kk || !P_kk) return RSLAM_ERR_ARG;
+    int rc = set_layout(c, layout);
+    if (rc) return rc;
+    rc = upload_xp(c, x_kk, P_kk, c->d_x2.p, c->d_P.p);
+    if (rc) return rc;
+    c->have_post = true; c->have_state = false; c->have_meas = false; c->predicted = false;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_ekf_prediction(rslam_ctx* c, double delta_t, double std_a, double std_alpha)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_post) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t nn = (size_t)c->NP * c->NP;
+    HIPCHK(hipMemcpyAsync(c->d_xpred.p, c->d_x2.p, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_Ppred.p, c->d_P.p, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+    launch_ekf_prediction(s, c->n, c->NP, c->d_x2.p, c->d_P.p, delta_t, std_a, std_alpha, c->d_xpred.p, c->d_Ppred.p, c->d_FQ.p);
+    HIPCHK(hipGetLastError());
+    c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_fetch_prior(rslam_ctx* c, double* x_pred, double* P_pred)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    if (x_pred) HIPCHK(hipMemcpyAsync(x_pred, c->d_xpred.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    if (P_pred) HIPCHK(hipMemcpy2DAsync(P_pred, sizeof(double) * c->n, c->d_Ppred.p, sizeof(double) * c->NP, sizeof(double) * c->n,
+                                        c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return RSLAM_OK;
 }
 

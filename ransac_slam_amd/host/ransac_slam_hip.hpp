@@ -69,6 +69,7 @@ public:
     VectorXd x_k_k, x_k_km1;
     MatrixXd p_k_k, p_k_km1;
     double std_z = 1.0;
+    double std_a = 0.007, std_alpha = 0.007;     // Sigma.a, Sigma.alpha (initialize_param.yaml:40-41)
 
     // n_draws: length of the draw list handed to the RANSAC loop per frame (>= the
     // reference's initial n_hyp = 1000, Tracking.cpp:357)
@@ -90,6 +91,24 @@ public:
 
     rslam_ctx* ctx() { return ctx_; }
     int n_draws() const { return n_draws_; }
+
+    // predict_state_and_covariance (ExtendKF.cpp:333-388) on the device.  map_changed = true
+    // when Map::map_management edited x_k_k / p_k_k on the host this frame (System.cpp:111):
+    // they are uploaded first; otherwise the posterior of the previous frame is still resident
+    // and nothing crosses PCIe.  The prior stays on the device for search_IC_matches_predict.
+    void ekf_prediction(bool map_changed, const std::vector<uint8_t>& type, const std::vector<int32_t>& offset)
+    {
+        int rc;
+        if (map_changed) {
+            rslam_layout lay{x_k_k.rows(), (int32_t)type.size(), type.data(), offset.data()};
+            rc = rslam_set_posterior(ctx_, &lay, x_k_k.data(), p_k_k.data());
+            if (rc) throw Error(rc, "rslam_set_posterior");
+        }
+        rc = rslam_ekf_prediction(ctx_, 1.0, std_a, std_alpha);
+        if (rc) throw Error(rc, "rslam_ekf_prediction");
+        prior_resident = true;
+    }
+    bool prior_resident = false;
 
     // Partial update using low-innovation inliers (ExtendKF.cpp:559-596).  The device
     // already ran both updates inside Tracking::ransac_hypotheses; this publishes nothing
@@ -137,7 +156,9 @@ public:
         rslam_layout lay{off, L, type_.data(), offset_.data()};
         std::vector<double> h(2 * (size_t)L + 1), S(4 * (size_t)L + 1);
         std::vector<uint8_t> vis((size_t)L + 1);
-        const int rc = rslam_predict(k.ctx(), &lay, k.x_k_km1.data(), k.p_k_km1.data(), h.data(), vis.data(), S.data());
+        const int rc = k.prior_resident
+            ? rslam_predict(k.ctx(), &lay, nullptr, nullptr, h.data(), vis.data(), S.data())
+            : rslam_predict(k.ctx(), &lay, k.x_k_km1.data(), k.p_k_km1.data(), h.data(), vis.data(), S.data());
         if (rc) throw Error(rc, "rslam_predict");
         for (int i = 0; i < L; ++i) {
             Feature& f = k.features_info[i];
