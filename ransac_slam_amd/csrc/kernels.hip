@@ -705,32 +705,27 @@ chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __re
                 const double x2 = fma(-c4.l21, x1, fma(-c4.l20, x0, a2)) * c4.r2;
                 const double x3 = fma(-c4.l32, x2, fma(-c4.l31, x1, fma(-c4.l30, x0, a3))) * c4.r3;
                 if (t < 64) {
-                    // rows of the pivot block hold L4 itself (x_k is then l_{row,k}, and 1/r on the diagonal)
-                    const bool below = e > p0 + 3, inblk = e >= p0;
+                    // rows of the pivot block hold L4 itself (x_k is then l_{row,k}); entries written
+                    // above the diagonal of L / right of the diagonal of L^-1 are never read
+                    const bool below = e > p0 + 3;
                     Xs[e] = below ? x0 : 0.0; Xs[64 + e] = below ? x1 : 0.0;
                     Xs[128 + e] = below ? x2 : 0.0; Xs[192 + e] = below ? x3 : 0.0;
-                    if (inblk) {
-                        const int d = e - p0;                         // >= 4 for rows below the block
-                        Lf[(p0 + 0) * CD_LD + e] = x0;
-                        if (d >= 1) Lf[(p0 + 1) * CD_LD + e] = x1;
-                        if (d >= 2) Lf[(p0 + 2) * CD_LD + e] = x2;
-                        if (d >= 3) Lf[(p0 + 3) * CD_LD + e] = x3;
-                    }
+                    Lf[(p0 + 0) * CD_LD + e] = x0; Lf[(p0 + 1) * CD_LD + e] = x1;
+                    Lf[(p0 + 2) * CD_LD + e] = x2; Lf[(p0 + 3) * CD_LD + e] = x3;
                 } else {
                     // column e of rows p0..p0+3 of L^-1 (final); nothing right of the pivot columns
                     const bool left = e <= p0 + 3;
-                    const double y0 = left ? x0 : 0.0, y1 = left ? x1 : 0.0, y2 = left ? x2 : 0.0, y3 = left ? x3 : 0.0;
-                    Ms[e] = y0; Ms[64 + e] = y1; Ms[128 + e] = y2; Ms[192 + e] = y3;
-                    if (left) {
-                        Mf[e * CD_LD + p0 + 0] = y0; Mf[e * CD_LD + p0 + 1] = y1;
-                        Mf[e * CD_LD + p0 + 2] = y2; Mf[e * CD_LD + p0 + 3] = y3;
-                    }
+                    Ms[e] = left ? x0 : 0.0; Ms[64 + e] = left ? x1 : 0.0;
+                    Ms[128 + e] = left ? x2 : 0.0; Ms[192 + e] = left ? x3 : 0.0;
+                    Mf[e * CD_LD + p0 + 0] = x0; Mf[e * CD_LD + p0 + 1] = x1;
+                    Mf[e * CD_LD + p0 + 2] = x2; Mf[e * CD_LD + p0 + 3] = x3;
                 }
             }
             CD_STAMP(s2);
             __syncthreads();
             CD_STAMP(s3);
             // ---- C: rank-4 updates of the owned tiles, one MFMA each
+            // (issuing the tiles that feed the next pivot block first was tried: slower code)
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 const int idx = wave + 4 * o;
