@@ -28,17 +28,17 @@ struct ScoreTables {          // per matched feature (rank j in feature order), 
     const int32_t* zsrc;      // feature whose z is compared (Q2 in compat mode)
 };
 
+// h_in / has_h_in: previous prediction (nullable); sel_reset: frame scalars to zero (nullable)
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
-                    const uint8_t* type, const int32_t* off, double* h, uint8_t* has_h,
-                    uint8_t* vis, double* H13, double* S, double radd);
+                    const uint8_t* type, const int32_t* off, const double* h_in, const uint8_t* has_h_in,
+                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset);
 
-void launch_innov(hipStream_t s, int m, const int32_t* mfeat, const double* S, const double* z,
-                  const double* h, const uint8_t* has_h, double* wv, int32_t* status);
-
-// out[:, 2c+p] = P[:, cols(list[c])] * H13[list[c]][p]^T for c < count
+// out[:, 2c+p] = P[:, cols(list[c])] * H13[list[c]][p]^T for c < count; with wv != nullptr also
+// wv[2c..] = S_f^-1 (z_f - h_f) (K3)
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count /* nullable */, const double* H13, const int32_t* off,
-                const uint8_t* type, double* out, long ldo);
+                const uint8_t* type, double* out, long ldo, const double* S, const double* z, const double* h,
+                const uint8_t* has_h, double* wv, int32_t* status);
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                   const double* wv, const ScoreTables& tab, const double* z, int m, int words,
@@ -48,14 +48,12 @@ void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* 
 void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos, int hb, int he,
                         int32_t* sup);
 
-void launch_select(hipStream_t s, const int32_t* sup, int H, const int32_t* nhyp_table,
-                   int adaptive, int n_hyp_init, int32_t* sel);
-
-// re-score the winning hypothesis and scatter its mask to li[], build list/count
+// K5: consensus replay over the full support list, then re-score the winning hypothesis and
+// scatter its mask to li[], build list/count
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int cap_blocks, int32_t* sel, uint8_t* li,
-                      int32_t* list);
+                      int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init);
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
                         const double* S, const double* z, const double* h, double chi2, int cap_blocks,
@@ -63,11 +61,11 @@ void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* 
 
 struct SystemDims { int n, NP, RP, ldA; };   // stacked matrix A: rows [0,RP) S | [RP,RP+NP) W | RP+NP: nu^T (+63 pad)
 
-void launch_gather_w(hipStream_t s, const SystemDims& d, const double* W, const int32_t* rank_of,
-                     const int32_t* list, const int32_t* sel, int slot_k, int slot_nblk, double* A);
+// Wsrc != nullptr: the P*H^T columns are gathered from the matched-feature matrix first (LI pass)
 void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* list, const int32_t* sel,
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
-                           const uint8_t* type, const double* z, const double* h, double* A);
+                           const uint8_t* type, const double* z, const double* h, double* A,
+                           const double* Wsrc, const int32_t* rank_of);
 void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
                          int slot_k, int slot_nblk, int cap_blocks, double* A, double* Linv, int32_t* status_sel);
 void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,

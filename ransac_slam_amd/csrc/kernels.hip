@@ -29,9 +29,11 @@ namespace rslam {
 __global__ void __launch_bounds__(64)
 predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ P, int NP, int L,
                const uint8_t* __restrict__ type, const int32_t* __restrict__ off,
-               double* h, uint8_t* has_h, uint8_t* vis, double* __restrict__ H13, double* __restrict__ S,
-               double radd)
+               const double* __restrict__ h_in, const uint8_t* __restrict__ has_h_in,   // nullable: no previous h
+               double* __restrict__ h, uint8_t* __restrict__ has_h, uint8_t* vis, double* __restrict__ H13,
+               double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */)
 {
+    if (sel_reset && blockIdx.x == 0 && threadIdx.x < SEL_COUNT) sel_reset[threadIdx.x] = 0;   // new frame
     const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
     const int sub = threadIdx.x & 15;
     if (i >= L) return;                       // whole 16-lane group leaves together
@@ -39,11 +41,13 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
     const int o = off[i];
     double u, v;
     const bool visible = predict_feature(cam, x, o, is_id, u, v);
-    const bool have = visible || (has_h[i] != 0);
+    const bool had = has_h_in && (has_h_in[i] != 0);
+    const bool have = visible || had;
     double hu_ = u, hv_ = v;
-    if (!visible && have) { hu_ = h[2 * i]; hv_ = h[2 * i + 1]; }     // stale h (ExtendKF.cpp:77-78)
+    if (!visible && had) { hu_ = h_in[2 * i]; hv_ = h_in[2 * i + 1]; }    // stale h (ExtendKF.cpp:77-78)
     if (sub == 0) {
-        if (visible) { h[2 * i] = u; h[2 * i + 1] = v; has_h[i] = 1; }
+        if (have) { h[2 * i] = hu_; h[2 * i + 1] = hv_; }
+        has_h[i] = have ? 1 : 0;
         if (vis) vis[i] = visible ? 1 : 0;
     }
     if (!have) return;
@@ -80,58 +84,51 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
 }
 
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
-                    const uint8_t* type, const int32_t* off, double* h, uint8_t* has_h,
-                    uint8_t* vis, double* H13, double* S, double radd)
+                    const uint8_t* type, const int32_t* off, const double* h_in, const uint8_t* has_h_in,
+                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset)
 {
-    if (L <= 0) return;
-    predict_kernel<<<dim3((L + 3) / 4), dim3(64), 0, s>>>(cam, x, P, NP, L, type, off, h, has_h, vis, H13, S, radd);
-}
-
-// ---------------------------------------------------------------------------
-// K3: w_j = S_j^-1 (z_j - h_j) for every matched feature.  The hypothesis
-// state of Tracking.cpp:420-422 is then xi = x + (P H_j^T) w_j, so the gain
-// K = P H^T S^-1 is never materialised.
-// ---------------------------------------------------------------------------
-__global__ void innov_kernel(int m, const int32_t* __restrict__ mfeat, const double* __restrict__ S,
-                             const double* __restrict__ z, const double* __restrict__ h,
-                             const uint8_t* __restrict__ has_h, double* __restrict__ wv, int32_t* __restrict__ status)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const int f = mfeat[j];
-    if (!has_h[f]) {                        // matching() only produces z where h exists (Tracking.cpp:293)
-        atomicMin(status, -7);              // RSLAM_ERR_IC_NOT_VISIBLE
-        wv[2 * j] = 0.0; wv[2 * j + 1] = 0.0;
+    if (L <= 0) {
+        if (sel_reset) (void)hipMemsetAsync(sel_reset, 0, sizeof(int32_t) * SEL_COUNT, s);
         return;
     }
-    double Si[4] = { S[4 * f], S[4 * f + 1], S[4 * f + 2], S[4 * f + 3] }, Sinv[4];
-    inv2_lu(Si, Sinv);
-    const double n0 = z[2 * f] - h[2 * f], n1 = z[2 * f + 1] - h[2 * f + 1];
-    wv[2 * j]     = Sinv[0] * n0 + Sinv[2] * n1;
-    wv[2 * j + 1] = Sinv[1] * n0 + Sinv[3] * n1;
-}
-
-void launch_innov(hipStream_t s, int m, const int32_t* mfeat, const double* S, const double* z,
-                  const double* h, const uint8_t* has_h, double* wv, int32_t* status)
-{
-    if (m <= 0) return;
-    innov_kernel<<<dim3((m + 63) / 64), dim3(64), 0, s>>>(m, mfeat, S, z, h, has_h, wv, status);
+    predict_kernel<<<dim3((L + 3) / 4), dim3(64), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
+                                                        sel_reset);
 }
 
 // ---------------------------------------------------------------------------
 // K2: out[:, 2c+p] = sum_k P[:, col_k] * H13[f][p][k] over the 13 (10) non-zero
 // columns of H_f (Tracking.cpp:42,420-421 do this as dense 2 x n products).
 // HBM-bound: every column of P that belongs to a listed feature is streamed once.
+// K3 rides along (first row block of each column): w_j = S_j^-1 (z_j - h_j); the hypothesis
+// state of Tracking.cpp:420-422 is then xi = x + (P H_j^T) w_j, the gain K = P H^T S^-1 is
+// never materialised.
 // ---------------------------------------------------------------------------
+struct InnovArgs {            // all nullable together
+    const double* S; const double* z; const double* h; const uint8_t* has_h; double* wv; int32_t* status;
+};
+
 __global__ void __launch_bounds__(256)
 pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ list, int max_count,
            const int32_t* __restrict__ d_count, const double* __restrict__ H13,
-           const int32_t* __restrict__ off, const uint8_t* __restrict__ type, double* __restrict__ out, long ldo)
+           const int32_t* __restrict__ off, const uint8_t* __restrict__ type, double* __restrict__ out, long ldo,
+           InnovArgs iv)
 {
     const int c = blockIdx.y;
     const int count = d_count ? *d_count : max_count;
     if (c >= count) return;
     const int f = list[c];
+    if (iv.wv && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!iv.has_h[f]) {                     // matching() only produces z where h exists (Tracking.cpp:293)
+            atomicMin(iv.status, -7);           // RSLAM_ERR_IC_NOT_VISIBLE
+            iv.wv[2 * c] = 0.0; iv.wv[2 * c + 1] = 0.0;
+        } else {
+            double Si[4] = { iv.S[4 * f], iv.S[4 * f + 1], iv.S[4 * f + 2], iv.S[4 * f + 3] }, Sinv[4];
+            inv2_lu(Si, Sinv);
+            const double n0 = iv.z[2 * f] - iv.h[2 * f], n1 = iv.z[2 * f + 1] - iv.h[2 * f + 1];
+            iv.wv[2 * c]     = Sinv[0] * n0 + Sinv[2] * n1;
+            iv.wv[2 * c + 1] = Sinv[1] * n0 + Sinv[3] * n1;
+        }
+    }
     const int o = off[f];
     const double* Hf = H13 + 26 * (long)f;
     const int row = blockIdx.x * 256 + threadIdx.x;
@@ -149,10 +146,12 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
 
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count, const double* H13, const int32_t* off, const uint8_t* type,
-                double* out, long ldo)
+                double* out, long ldo, const double* S, const double* z, const double* h, const uint8_t* has_h,
+                double* wv, int32_t* status)
 {
     if (max_count <= 0) return;
-    pht_kernel<<<dim3(NP / 256 + (NP % 256 ? 1 : 0), max_count), dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo);
+    InnovArgs iv{S, z, h, has_h, wv, status};
+    pht_kernel<<<dim3(NP / 256 + (NP % 256 ? 1 : 0), max_count), dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv);
 }
 
 // ---------------------------------------------------------------------------
@@ -285,24 +284,22 @@ void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos
 // loop state, so the block finds the records in parallel (prefix-max scan) and
 // one lane replays the loop over them.
 // ---------------------------------------------------------------------------
-constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAX_THREADS = 1024;
 constexpr int SEL_MAX_RECORDS = 4096;
 
-__global__ void __launch_bounds__(SEL_THREADS)
-select_kernel(const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table,
-              int adaptive, int n_hyp_init, int32_t* __restrict__ sel)
+// all threads of the block; blockDim.x <= SEL_MAX_THREADS; result in sel[0..2]
+__device__ void select_consensus(const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table,
+                                 int adaptive, int n_hyp_init, int32_t* __restrict__ sel,
+                                 int* s_max, int* s_cnt, int* s_rec)
 {
-    __shared__ int s_max[SEL_THREADS];
-    __shared__ int s_cnt[SEL_THREADS];
-    __shared__ int s_rec[SEL_MAX_RECORDS];
-    const int t = threadIdx.x;
-    const int chunk = (H + SEL_THREADS - 1) / SEL_THREADS;
-    const int lo = t * chunk, hi = min(H, lo + chunk);
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int chunk = (H + nt - 1) / nt;
+    const int lo = min(H, t * chunk), hi = min(H, lo + chunk);
     int mx = 0;
     for (int i = lo; i < hi; ++i) mx = max(mx, sup[i]);
     s_max[t] = mx;
     __syncthreads();
-    for (int d = 1; d < SEL_THREADS; d <<= 1) {        // inclusive prefix max
+    for (int d = 1; d < nt; d <<= 1) {                 // inclusive prefix max
         const int other = (t >= d) ? s_max[t - d] : 0;
         __syncthreads();
         s_max[t] = max(s_max[t], other);
@@ -313,7 +310,7 @@ select_kernel(const int32_t* __restrict__ sup, int H, const int32_t* __restrict_
     for (int i = lo; i < hi; ++i) { const int v = sup[i]; if (v > run) { run = v; ++cnt; } }
     s_cnt[t] = cnt;
     __syncthreads();
-    for (int d = 1; d < SEL_THREADS; d <<= 1) {        // inclusive prefix sum
+    for (int d = 1; d < nt; d <<= 1) {                 // inclusive prefix sum
         const int other = (t >= d) ? s_cnt[t - d] : 0;
         __syncthreads();
         s_cnt[t] += other;
@@ -327,7 +324,7 @@ select_kernel(const int32_t* __restrict__ sup, int H, const int32_t* __restrict_
     }
     __syncthreads();
     if (t == 0) {
-        const int nrec = min(s_cnt[SEL_THREADS - 1], SEL_MAX_RECORDS);
+        const int nrec = min(s_cnt[nt - 1], SEL_MAX_RECORDS);
         int n_hyp = adaptive ? n_hyp_init : H;
         int best = 0, besti = -1, evaluated = 0, last = 0;
         bool done = false;
@@ -347,12 +344,7 @@ select_kernel(const int32_t* __restrict__ sup, int H, const int32_t* __restrict_
         sel[SEL_BEST_SUPPORT] = best;
         sel[SEL_HYPS_EVALUATED] = evaluated;
     }
-}
-
-void launch_select(hipStream_t s, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive,
-                   int n_hyp_init, int32_t* sel)
-{
-    select_kernel<<<dim3(1), dim3(SEL_THREADS), 0, s>>>(sup, H, nhyp_table, adaptive, n_hyp_init, sel);
+    __syncthreads();
 }
 
 // ordered compaction helper: every thread contributes flag; returns its output
@@ -380,14 +372,20 @@ __global__ void __launch_bounds__(1024)
 best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
                  const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
                  const int32_t* __restrict__ pos, double thr, int L, int cap_blocks, int32_t* __restrict__ sel,
-                 uint8_t* __restrict__ li, int32_t* __restrict__ list)
+                 uint8_t* __restrict__ li, int32_t* __restrict__ list,
+                 const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table, int adaptive,
+                 int n_hyp_init)
 {
     __shared__ int s_wave[16];
     __shared__ int s_running;
+    __shared__ int s_max[SEL_MAX_THREADS];
+    __shared__ int s_cnt[SEL_MAX_THREADS];
+    __shared__ int s_rec[SEL_MAX_RECORDS];
+    select_consensus(sup, H, nhyp_table, adaptive, n_hyp_init, sel, s_max, s_cnt, s_rec);   // K5
     if (threadIdx.x == 0) s_running = 0;
     for (int i = threadIdx.x; i < L; i += blockDim.x) li[i] = 0;
     __syncthreads();
-    const int best = sel[SEL_BEST_HYP];
+    const int best = ((volatile int32_t*)sel)[SEL_BEST_HYP];
     if (best >= 0) {
         HypCtx hc;
         hyp_setup(x, W, NP, wv, pos[best], hc);
@@ -410,9 +408,12 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int cap_blocks, int32_t* sel, uint8_t* li,
-                      int32_t* list)
+                      int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init)
 {
-    best_mask_kernel<<<dim3(1), dim3(score_block_size(m)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, cap_blocks, sel, li, list);
+    int bs = score_block_size(m);
+    if (bs < 256) bs = 256;          // the consensus scan wants a few waves even for tiny maps
+    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, cap_blocks, sel, li, list,
+                                                  sup, H, nhyp_table, adaptive, n_hyp_init);
 }
 
 // ---------------------------------------------------------------------------
@@ -468,41 +469,22 @@ void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* 
 // (ExtendKF.cpp:565-594 stack z, h, H; :602 S = H P H^T + I).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-gather_w_kernel(SystemDims d, const double* __restrict__ W, const int32_t* __restrict__ rank_of,
-                const int32_t* __restrict__ list, const int32_t* __restrict__ sel, int slot_k, int slot_nblk,
-                double* __restrict__ A)
-{
-    const int c = blockIdx.y;
-    if (c >= 64 * sel[slot_nblk]) return;
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= d.NP) return;
-    const int k = sel[slot_k];
-    double v = 0.0;
-    if (c < 2 * k) {
-        const int src = 2 * rank_of[list[c >> 1]] + (c & 1);
-        v = W[row + (long)src * d.NP];
-    }
-    A[d.RP + row + (long)c * d.ldA] = v;
-}
-
-void launch_gather_w(hipStream_t s, const SystemDims& d, const double* W, const int32_t* rank_of,
-                     const int32_t* list, const int32_t* sel, int slot_k, int slot_nblk, double* A)
-{
-    if (d.RP <= 0) return;
-    gather_w_kernel<<<dim3((d.NP + 255) / 256, d.RP), dim3(256), 0, s>>>(d, W, rank_of, list, sel, slot_k, slot_nblk, A);
-}
-
-__global__ void __launch_bounds__(256)
 prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int32_t* __restrict__ sel,
                       int slot_k, int slot_nblk, const double* __restrict__ H13, const int32_t* __restrict__ off,
                       const uint8_t* __restrict__ type,
-                      const double* __restrict__ z, const double* __restrict__ h, double* __restrict__ A)
+                      const double* __restrict__ z, const double* __restrict__ h, double* __restrict__ A,
+                      const double* __restrict__ Wsrc /* nullable */, const int32_t* __restrict__ rank_of)
 {
     const int c = blockIdx.x;
     if (c >= 64 * sel[slot_nblk]) return;
     const int r = 2 * sel[slot_k];
     double* col = A + (long)c * d.ldA;
-    const double* wcol = col + d.RP;            // P*H^T column c (already in place)
+    double* wcol = col + d.RP;                  // P*H^T column c
+    if (Wsrc && c < r) {                        // low-innovation pass: gather it from the matched-feature P*H^T
+        const double* src = Wsrc + (long)(2 * rank_of[list[c >> 1]] + (c & 1)) * d.NP;
+        for (int a = threadIdx.x; a < d.NP; a += 256) wcol[a] = src[a];
+        __syncthreads();                        // the block re-reads its own column below
+    }
     for (int a = threadIdx.x; a < d.RP; a += 256) {
         double v = (a == c) ? 1.0 : 0.0;        // + R = I (ExtendKF.cpp:594); identity on the padding
         if (c < r && a < r) {
@@ -529,10 +511,11 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
 
 void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* list, const int32_t* sel,
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
-                           const uint8_t* type, const double* z, const double* h, double* A)
+                           const uint8_t* type, const double* z, const double* h, double* A,
+                           const double* Wsrc, const int32_t* rank_of)
 {
     if (d.RP <= 0) return;
-    prepare_system_kernel<<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A);
+    prepare_system_kernel<<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A, Wsrc, rank_of);
 }
 
 // ---------------------------------------------------------------------------
@@ -834,16 +817,19 @@ trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     const double* Ai = A + (long)i * 64 + (long)step * 64 * ldA;
     const double* Aj = A + (long)j * 64 + (long)step * 64 * ldA;
     double* C = A + (long)i * 64 + (long)j * 64 * ldA;
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double cin[16];                                   // the tile to update: in flight under the product
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cin[q] = C[row + (long)(g + 4 * q) * ldA];
     d4 acc[2][2];
     tg_zero(acc);
     tile_gemm_nt(Ai, ldA, Aj, ldA, 64, lds, acc);
     tg_acc_to_lds(acc, lds, 1.0);
     __syncthreads();
-    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
-#pragma unroll 4
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = g + 4 * q;
-        C[row + (long)c * ldA] -= lds[c * TS_LD + row];
+        C[row + (long)c * ldA] = cin[q] - lds[c * TS_LD + row];
     }
 }
 

@@ -341,10 +341,10 @@ static int enqueue_predict(rslam_ctx* c)
     if (!c->have_state) return RSLAM_ERR_STATE;
     hipStream_t s = c->stream;
     mark(c, EV_START);
-    HIPCHK(hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, s));
-    if (c->L > 0) HIPCHK(hipMemsetAsync(c->d_hash.p, 0, c->L, s));     // Map.cpp:51 resets h every frame
-    launch_predict(s, c->cam, c->d_xpred.p, c->d_Ppred.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
-                   c->d_vis.p, c->d_H13.p, c->d_S.p, 1.0 /* features_info[i].R = I, Map.cpp:310 */);
+    // no previous h: Map.cpp:51 resets it every frame; the kernel also zeroes the frame scalars
+    launch_predict(s, c->cam, c->d_xpred.p, c->d_Ppred.p, c->NP, c->L, c->d_type.p, c->d_off.p, nullptr, nullptr,
+                   c->d_h.p, c->d_hash.p, c->d_vis.p, c->d_H13.p, c->d_S.p, 1.0 /* features_info[i].R = I, Map.cpp:310 */,
+                   c->d_sel.p);
     mark(c, EV_PREDICT);
     c->predicted = true; c->pht_done = false; c->dedup_done = false;
     return RSLAM_OK;
@@ -356,9 +356,8 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     if (hb < 0 || he > c->H || hb > he || !d_sup) return RSLAM_ERR_ARG;
     hipStream_t s = c->stream;
     if (!c->pht_done) {
-        launch_innov(s, c->m, c->d_mfeat.p, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
-                   c->d_W.p, c->NP);
+                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
         c->pht_done = true;
     }
     mark(c, EV_PHT);
@@ -381,14 +380,16 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     return RSLAM_OK;
 }
 
-static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int cap, const double* H13,
+static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int cap, const double* Wsrc,
+                              const double* H13,
                               const double* z_h, const double* x_in, double* x_out, const double* Pin, double* Pout,
                               int ev_f0, int ev_f1, int ev_r0, int ev_r1)
 {
     hipStream_t s = c->stream;
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
     int32_t* sel = c->d_sel.p;
-    launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p);
+    launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p,
+                          Wsrc, c->d_rank_of.p);
     if (ev_f0 >= 0) mark(c, ev_f0);
     {
         const size_t need = 2 * (size_t)(c->RP / 64 + 1);
@@ -423,38 +424,33 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     int32_t* sel = c->d_sel.p;
     c->last_sup = d_sup;
     if (!c->pht_done) {   // update without a local score pass (supports came from elsewhere)
-        launch_innov(s, c->m, c->d_mfeat.p, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
-                   c->d_W.p, c->NP);
+                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
         c->pht_done = true;
     }
     // K5 consensus (Tracking.cpp:507-537)
-    launch_select(s, d_sup, c->H, c->d_nhyp.p, c->cfg.adaptive, c->cfg.n_hyp_init, sel);
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
-                     c->cfg.sigma_z, c->L, c->cap_li, sel, c->d_li.p, c->d_lilist.p);
+                     c->cfg.sigma_z, c->L, c->cap_li, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
+                     c->cfg.adaptive, c->cfg.n_hyp_init);
     mark(c, EV_SELECT);
     // low-innovation update (ExtendKF.cpp:559-596)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
-    launch_gather_w(s, d, c->d_W.p, c->d_rank_of.p, c->d_lilist.p, sel, SEL_K_LI, SEL_NBLK_LI, c->d_A.p);
-    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, c->cap_li, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
+    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, c->cap_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
                                 c->d_Ppred.p, c->d_P.p, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0, EV_LI_RANK1);
     if (rc) return rc;
     mark(c, EV_LI_END);
     // rescue (Tracking.cpp:574-597): re-predict at x_k_k; invisible features keep their stale h
-    if (c->L > 0) {
-        HIPCHK(hipMemcpyAsync(c->d_h2.p, c->d_h.p, sizeof(double) * 2 * c->L, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->d_hash2.p, c->d_hash.p, c->L, hipMemcpyDeviceToDevice, s));
-    }
-    launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h2.p, c->d_hash2.p, nullptr,
-                   c->d_H13b.p, c->d_S2.p, c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */);
+    launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
+                   c->d_h2.p, c->d_hash2.p, nullptr, c->d_H13b.p, c->d_S2.p,
+                   c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr);
     launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
                        c->cap_hi, c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
     if (c->RP > 0)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
-                   c->d_A.p + c->RP, c->ldA);
-    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->cap_hi, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
+                   c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->cap_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);

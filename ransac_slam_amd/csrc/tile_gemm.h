@@ -160,6 +160,20 @@ __device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ A, long 
     double* Bs1 = lds + 3 * TG_OPER_DOUBLES;
     const int nchunks = K / TG_KC;
     if (nchunks <= 0) return;
+    if (nchunks == 2) {
+        // K = 64 (panel solve / trailing update of the factor sweep): both chunks fit the two
+        // buffers, so all global loads are issued at once and there is a single fill latency
+        TileRegs r0, r1;
+        tg_load_chunk(A, lda, B, ldb, 0, r0);
+        tg_load_chunk(A, lda, B, ldb, TG_KC, r1);
+        tg_store_chunk(As0, Bs0, r0);
+        tg_store_chunk(As1, Bs1, r1);
+        __syncthreads();
+        tg_compute_chunk(As0, Bs0, acc);
+        tg_compute_chunk(As1, Bs1, acc);
+        __syncthreads();
+        return;
+    }
     TileRegs r;
     tg_load_chunk(A, lda, B, ldb, 0, r);
     tg_store_chunk(As0, Bs0, r);
