@@ -31,6 +31,22 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_bench_c3_pmc_summary.csv")
+
+
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command at C3, profiles/README.md):
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reports half the bytes of coalesced reads on
+    gfx950 (MI355X_MICROARCH.md, HBM section; confirmed on pht_kernel).  'max' = the large (HI) pass."""
+    import csv
+    try:
+        rows = [r for r in csv.DictReader(open(PMC_SUMMARY)) if kernel_substr in r["kernel"]]
+        fetch = max(float(r["max"]) for r in rows if r["counter"] == "FETCH_SIZE")
+        write = max(float(r["max"]) for r in rows if r["counter"] == "WRITE_SIZE")
+        return (2.0 * fetch + write) * 1024.0
+    except Exception:
+        return None
 
 
 def cpu_baseline(frame, cfg, sample_iters):
@@ -190,13 +206,19 @@ def main():
         flops = float(n) * (n + 1) * r            # lower-triangle tiles only: n(n+1)r (SURVEY 8d F_rank)
         achieved = flops / (us * 1e-6) * 1e-12 if us > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                           "traffic": pmc_traffic_bytes("rank_update_kernel") if args.workload == "C3" else None,
+                           "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes committed under profiles/ "
+                                           "(not collectable inside this process); algorithmic bytes: read P + Y, write P",
+                           "algorithmic_bytes_per_launch": 8.0 * (2.0 * n * n + n * r),
                            "algorithmic_flops_per_launch": flops, "launch_us": us, "rank_r": r,
                            "note": "n(n+1)r flops of P - Y Y^T on lower-triangle tile pairs; launch duration from "
                                    "hipEvents bracketing the kernel on its stream, mean of %d eager frames" % nrep}
         if not args.no_extras:
-            out["probes"] = {"mfma_f64_1wave_per_simd": ctx.mfma_f64_probe(1),
-                             "mfma_f64_2waves_per_simd": ctx.mfma_f64_probe(2),
+            out["probes"] = {"mfma_f64_16x16x4_1wave_per_simd": ctx.mfma_f64_probe(1, 0),
+                             "mfma_f64_16x16x4_2waves_per_simd": ctx.mfma_f64_probe(2, 0),
+                             "mfma_f64_4x4x4_4b_2waves_per_simd": ctx.mfma_f64_probe(2, 2),
+                             "mfma_f64_4x4x4_4b_8waves_per_simd": ctx.mfma_f64_probe(8, 2),
                              "hbm_copy_GBps": ctx.hbm_copy_peak(1 << 30)}
             # algorithmic bytes of K4: 96 B per hypothesis x feature pair (SURVEY 8d B_score)
             b_score = H_total * m * 96.0

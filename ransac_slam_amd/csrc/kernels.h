@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "camera_model.h"
 
 namespace rslam {
@@ -73,7 +74,9 @@ void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel,
 // C = sym(Pin) - Y Y^T on the lower-triangle tile pairs (K from sel[slot_nblk]*64);
 // K == 0: C = Pin exactly (ExtendKF.cpp:635-638 pass-through)
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
-                        const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo);
+                        const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
+                        const int32_t* tile_order /* nullable: row-major triangle */);
+void make_rank_update_order(int nT, std::vector<int32_t>& order);   // XCD-aware (bi << 16 | bj) per block
 void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_k, const double* T, double* P);
 
 // x_pred[0:13], FQ (338 doubles) and the 13-row/column strips of P_pred; the caller copies

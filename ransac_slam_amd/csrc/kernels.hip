@@ -14,6 +14,7 @@
 // K12 rescue_gate_kernel    chi-square gate of the high-innovation candidates
 #include "kernels.h"
 #include "tile_gemm.h"
+#include <vector>
 
 namespace rslam {
 
@@ -945,15 +946,24 @@ void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel,
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
-                   const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo)
+                   const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
+                   const int32_t* __restrict__ tile_order)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    // linear index -> (bi >= bj), row-major over the lower triangle
-    const int t = blockIdx.x;
-    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((long)bi * (bi + 1) / 2 > t) --bi;
-    while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    const int bj = t - bi * (bi + 1) / 2;
+    int bi, bj;
+    if (tile_order) {
+        // XCD-aware order (make_rank_update_order): the tiles one XCD's L2 sees form 8 x 8 regions of
+        // the triangle, so it fetches ~16 of the Y row panels instead of all of them
+        const int e = tile_order[blockIdx.x];
+        bi = e >> 16; bj = e & 0xffff;
+    } else {
+        // linear index -> (bi >= bj), row-major over the lower triangle
+        const int t = blockIdx.x;
+        bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long)bi * (bi + 1) / 2 > t) --bi;
+        while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        bj = t - bi * (bi + 1) / 2;
+    }
     (void)nT;
     const int K = (fixed_k >= 0) ? fixed_k : 64 * sel[slot_nblk];
     const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -1002,14 +1012,33 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     }
 }
 
+// Tile order for rank_update_kernel.  Workgroups are dealt round-robin over the 8 XCDs (block b
+// and b + 8 share an L2; speed only, never correctness), so entry b holds the b/8-th tile of the
+// (b % 8)-th contiguous slice of a region-major enumeration: 8 x 8 regions of the lower triangle.
+void make_rank_update_order(int nT, std::vector<int32_t>& order)
+{
+    std::vector<int32_t> seq;
+    for (int sr = 0; sr < nT; sr += 8)
+        for (int sc = 0; sc <= sr; sc += 8)
+            for (int bi = sr; bi < sr + 8 && bi < nT; ++bi)
+                for (int bj = sc; bj < sc + 8 && bj <= bi; ++bj) seq.push_back((bi << 16) | bj);
+    const int T = (int)seq.size(), q = T / 8, r = T % 8;
+    order.assign(T, 0);
+    for (int b = 0; b < T; ++b) {
+        const int x = b % 8, idx = b / 8;
+        order[b] = seq[x * q + (x < r ? x : r) + idx];
+    }
+}
+
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
-                        const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo)
+                        const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
+                        const int32_t* tile_order)
 {
     const int nT = NP / 64;
     const int tiles = nT * (nT + 1) / 2;
     if (tiles <= 0) return;
     rank_update_kernel<<<dim3(tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
-                                                                                  fixed_k, Pout, ldo);
+                                                                                  fixed_k, Pout, ldo, tile_order);
 }
 
 // ---------------------------------------------------------------------------

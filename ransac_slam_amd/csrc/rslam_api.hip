@@ -67,6 +67,8 @@ struct rslam_ctx {
     std::vector<int32_t> h_off;
     // device buffers
     DevBuf<uint8_t> d_type, d_vis, d_hash, d_hash2, d_ic, d_li, d_hi, d_mtype;
+    DevBuf<int32_t> d_tile_order;
+    int tile_order_nT = 0;
     DevBuf<int32_t> d_off, d_mfeat, d_moff, d_mith, d_miph, d_mzsrc, d_rank_of, d_pos, d_nhyp,
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
@@ -156,7 +158,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_xpred.release(); c->d_Ppred.release(); c->d_h.release(); c->d_h2.release(); c->d_H13.release();
     c->d_H13b.release(); c->d_S.release(); c->d_S2.release(); c->d_z.release(); c->d_wv.release();
     c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
-    c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release();
+    c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -241,6 +243,8 @@ static int upload_state(rslam_ctx* c, const rslam_layout* lay, const double* x_p
     return RSLAM_OK;
 }
 
+static const int32_t* tile_order(rslam_ctx* c, int NP);
+
 // Builds the gather tables that replace Converter::find/select/repmat
 // (Converter.cpp:210-287 as used at Tracking.cpp:361-397,413-415,443-448).
 static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic, const double* draws, int n_draws,
@@ -319,6 +323,7 @@ static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic,
         HIPCHK(hipMemcpyAsync(c->d_ic.p, ic, L, hipMemcpyHostToDevice, s));
     }
     HIPCHK(hipStreamSynchronize(s));
+    (void)tile_order(c, c->NP);          // never inside a graph capture
     c->have_meas = true; c->pht_done = false; c->dedup_done = false;
     return RSLAM_OK;
 }
@@ -380,6 +385,24 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     return RSLAM_OK;
 }
 
+// XCD-aware tile order of the covariance rank update for the current NP (built once per size)
+static const int32_t* tile_order(rslam_ctx* c, int NP)
+{
+    const int nT = NP / 64;
+    if (nT <= 0) return nullptr;
+    if (nT > 48) return nullptr;         // measured: beyond ~3000 states the plain row-major order is 3 % faster
+    if (c->tile_order_nT != nT) {
+        std::vector<int32_t> order;
+        make_rank_update_order(nT, order);
+        if (c->d_tile_order.ensure(order.size()) < 0) return nullptr;
+        if (hipMemcpy(c->d_tile_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return nullptr;
+        c->tile_order_nT = nT;
+        invalidate_graph(c);
+    }
+    return c->d_tile_order.p;
+}
+
 static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int cap, const double* Wsrc,
                               const double* H13,
                               const double* z_h, const double* x_in, double* x_out, const double* Pin, double* Pout,
@@ -410,7 +433,8 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
     }
     if (ev_r0 >= 0) mark(c, ev_r0);
-    launch_rank_update(s, c->NP, Pin, c->NP, c->d_A.p + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP);
+    launch_rank_update(s, c->NP, Pin, c->NP, c->d_A.p + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
+                       (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr);
     if (ev_r1 >= 0) mark(c, ev_r1);
     if (c->RP > 0) launch_quat_cov(s, c->n, c->NP, sel, slot_k, c->d_T.p, Pout);
     return RSLAM_OK;
@@ -785,7 +809,7 @@ extern "C" int rslam_k_rank_update(rslam_ctx* c, int32_t n, int32_t r, const dou
     const int NP = round_up(n, 64), K = round_up(r, TG_KC_HOST);
     if (lda < NP || ldc < NP || ldy < NP) return RSLAM_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc);
+    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc, tile_order(c, NP));
     HIPCHK(hipGetLastError());
     return RSLAM_OK;
 }
