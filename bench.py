@@ -136,7 +136,7 @@ def main():
     if world > 1:
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
-        sharded = ShardedFrame(HipEngine(ctx, local_rank))
+        sharded = ShardedFrame(HipEngine(ctx, local_rank, use_graph=not args.no_graph))
 
         def step():
             sharded.step()
@@ -179,7 +179,8 @@ def main():
             "config": {"workload": wl["name"], "landmarks": wl["L"], "state_dim": int(frame.n),
                        "matched_features": m, "hypotheses_total": H_total, "hypotheses_per_gpu": H_local,
                        "compat": args.compat, "adaptive": 0, "dedup": args.dedup,
-                       "launch": "hipGraph replay" if use_graph else "eager stream",
+                       "launch": ("eager stream" if args.no_graph else
+                                  ("hipGraph replay" if world == 1 else "two hipGraphs per frame around the all-gather")),
                        "parallelism": f"hypothesis-sharded x{world}, replicated update" if world > 1 else "single GPU"},
             "frames_per_s": args.steps / elapsed,
             "result": {k: int(res[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")},

@@ -175,6 +175,12 @@ int rslam_step_update(rslam_ctx* ctx, const int32_t* d_supports);
  * context-owned support buffer; replayed from a hipGraph when use_graph != 0. */
 int rslam_step_frame(rslam_ctx* ctx, int32_t use_graph);
 
+/* The same frame in two hipGraph-replayed halves for the hypothesis-sharded (multi-GPU) case:
+ * phase 0 = step_predict + step_score(hyp_begin, hyp_end), phase 1 = step_update; the caller
+ * exchanges the supports (e.g. RCCL all-gather) between the two.  d_supports is a DEVICE pointer. */
+int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t hyp_end,
+                     int32_t* d_supports, int32_t use_graph);
+
 /* Block until the stream is idle; returns the device-side status of the
  * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...). */
 int rslam_sync(rslam_ctx* ctx);

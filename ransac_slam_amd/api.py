@@ -40,6 +40,7 @@ SYMBOLS = {
     "rslam_step_predict": (C.c_int, [C.c_void_p]),
     "rslam_step_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rslam_step_update": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rslam_step_phase": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "rslam_step_frame": (C.c_int, [C.c_void_p, C.c_int32]),
     "rslam_sync": (C.c_int, [C.c_void_p]),
     "rslam_fetch_prediction": (C.c_int, [C.c_void_p, _dp, _u8p, _dp]),
@@ -188,6 +189,10 @@ class RslamHip:
 
     def step_update(self, d_supports_ptr):
         _chk(lib().rslam_step_update(self._h, C.c_void_p(d_supports_ptr)), "rslam_step_update")
+
+    def step_phase(self, phase, hyp_begin, hyp_end, d_supports_ptr, use_graph=True):
+        _chk(lib().rslam_step_phase(self._h, phase, hyp_begin, hyp_end, C.c_void_p(d_supports_ptr), 1 if use_graph else 0),
+             "rslam_step_phase")
 
     def step_frame(self, use_graph=True):
         _chk(lib().rslam_step_frame(self._h, 1 if use_graph else 0), "rslam_step_frame")

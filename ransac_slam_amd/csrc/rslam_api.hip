@@ -80,9 +80,13 @@ struct rslam_ctx {
     bool ev_ok = false;
     rslam_stage_times times;
     // graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_valid = false;
+    // hipGraph slots: 0 = whole frame, 1 = predict + score of a hypothesis slice, 2 = update stage
+    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
+    bool graph_valid[3] = {false, false, false};
+    int g1_hb = -1, g1_he = -1;
+    const void* g1_sup = nullptr;
+    const void* g2_sup = nullptr;
     // Factor-sweep launch sizing: the number of block steps enqueued per update follows the
     // previous frame's inlier counts (+1 block of slack); the device flags an overflow
     // (STATUS_SWEEP_CAP) and the update stage is then re-run with the full-length sequence.
@@ -93,9 +97,11 @@ struct rslam_ctx {
 
 static void invalidate_graph(rslam_ctx* c)
 {
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
-    c->graph_valid = false;
+    for (int k = 0; k < 3; ++k) {
+        if (c->graph_exec[k]) { (void)hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; }
+        if (c->graph[k]) { (void)hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; }
+        c->graph_valid[k] = false;
+    }
 }
 
 extern "C" const char* rslam_version(void) { return "rslam-hip 0.1 (gfx950)"; }
@@ -728,24 +734,63 @@ static int enqueue_frame(rslam_ctx* c)
     return enqueue_update(c, c->d_sup.p);
 }
 
+// capture `enqueue` into graph slot k (once) and replay it
+template <typename F>
+static int replay(rslam_ctx* c, int k, F enqueue)
+{
+    if (!c->graph_valid[k]) {
+        if (c->graph_exec[k]) { (void)hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; }
+        if (c->graph[k]) { (void)hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; }
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue();
+        const hipError_t e = hipStreamEndCapture(c->stream, &c->graph[k]);
+        if (rc) { if (c->graph[k]) { (void)hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; } return rc; }
+        if (e != hipSuccess || !c->graph[k]) { ctx_last_hip_error = (int)e; return RSLAM_ERR_HIP; }
+        HIPCHK(hipGraphInstantiate(&c->graph_exec[k], c->graph[k], nullptr, nullptr, 0));
+        c->graph_valid[k] = true;
+    }
+    HIPCHK(hipGraphLaunch(c->graph_exec[k], c->stream));
+    return RSLAM_OK;
+}
+
 extern "C" int rslam_step_frame(rslam_ctx* c, int32_t use_graph)
 {
     if (!c) return RSLAM_ERR_ARG;
     if (!c->have_state || !c->have_meas) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     if (!use_graph || c->timing) return enqueue_frame(c);
-    if (!c->graph_valid) {
-        invalidate_graph(c);
-        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_frame(c);
-        hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
-        if (rc) { if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; } return rc; }
-        if (e != hipSuccess || !c->graph) { ctx_last_hip_error = (int)e; return RSLAM_ERR_HIP; }
-        HIPCHK(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
-        c->graph_valid = true;
+    const int rc = replay(c, 0, [&]() { return enqueue_frame(c); });
+    if (rc) return rc;
+    c->predicted = true; c->pht_done = true; c->last_sup = c->d_sup.p;
+    return RSLAM_OK;
+}
+
+// Multi-GPU frame in two replayed graphs with the caller's exchange of supports in between:
+// phase 0 = predict + score of [hyp_begin, hyp_end), phase 1 = consensus + updates.
+extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, int32_t hyp_end, int32_t* d_supports,
+                                int32_t use_graph)
+{
+    if (!c || !d_supports || phase < 0 || phase > 1) return RSLAM_ERR_ARG;
+    if (!c->have_state || !c->have_meas) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    if (phase == 0) {
+        auto work = [&]() { int rc = enqueue_predict(c); if (rc) return rc; return enqueue_score(c, hyp_begin, hyp_end, d_supports); };
+        if (!use_graph || c->timing) return work();
+        if (c->g1_hb != hyp_begin || c->g1_he != hyp_end || c->g1_sup != d_supports) {
+            c->graph_valid[1] = false; c->g1_hb = hyp_begin; c->g1_he = hyp_end; c->g1_sup = d_supports;
+        }
+        const int rc = replay(c, 1, work);
+        if (rc) return rc;
+        c->predicted = true; c->pht_done = true;
+        return RSLAM_OK;
     }
-    HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
-    c->predicted = true; c->pht_done = true;
+    if (!c->predicted) return RSLAM_ERR_STATE;
+    auto work = [&]() { return enqueue_update(c, d_supports); };
+    if (!use_graph || c->timing) return work();
+    if (c->g2_sup != d_supports) { c->graph_valid[2] = false; c->g2_sup = d_supports; }
+    const int rc = replay(c, 2, work);
+    if (rc) return rc;
+    c->last_sup = d_supports; c->have_post = true;
     return RSLAM_OK;
 }
 

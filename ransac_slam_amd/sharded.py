@@ -52,21 +52,28 @@ class ShardedFrame:
     def step(self):
         """One frame: predict, score own slice, exchange, consensus + updates."""
         e = self.engine
-        e.step_predict()
-        e.step_score(self.begin, self.end, self.local)
+        if hasattr(e, "step_phase"):              # engines that replay each half from a hipGraph
+            e.step_phase(0, self.begin, self.end, self.local)
+        else:
+            e.step_predict()
+            e.step_score(self.begin, self.end, self.local)
+        full = self.local
         if self.world > 1:
             dist.all_gather_into_tensor(self.all, self.local, group=self.group)
-            e.step_update(self.all)
+            full = self.all
+        if hasattr(e, "step_phase"):
+            e.step_phase(1, self.begin, self.end, full)
         else:
-            e.step_update(self.local)
+            e.step_update(full)
 
 
 class HipEngine:
     """The product engine: ransac_slam_amd.api.RslamHip on this rank's GPU, enqueued
     on torch's current stream so that the RCCL all-gather is ordered with the kernels."""
 
-    def __init__(self, ctx, device_index: int):
+    def __init__(self, ctx, device_index: int, use_graph: bool = True):
         self.ctx = ctx
+        self.use_graph = use_graph
         self.device = torch.device("cuda", device_index)
         ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -83,3 +90,8 @@ class HipEngine:
 
     def step_update(self, supports_all):
         self.ctx.step_update(supports_all.data_ptr())
+
+    def step_phase(self, phase, hyp_begin, hyp_end, tensor):
+        # phase 0 writes tensor[0 : end-begin] (the C ABI indexes by global hypothesis id), phase 1 reads the full list
+        ptr = tensor.data_ptr() - 4 * hyp_begin if phase == 0 else tensor.data_ptr()
+        self.ctx.step_phase(phase, hyp_begin, hyp_end, ptr, self.use_graph)

@@ -266,6 +266,30 @@ def test_sweep_launch_sizing_overflow_reruns(hip, oracle_lib):
     g.close()
 
 
+def test_two_phase_graph_frame_equals_full(hip):
+    """The multi-GPU frame (two replayed graphs around the exchange) on one GPU, slice = everything."""
+    import torch
+    fr = make_frame(L=60, H=200, seed=303)
+    c = hip.RslamHip(default_config(compat=0, adaptive=1))
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    c.step_frame(False); c.sync()
+    full = c.fetch_results()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        c.set_stream(stream.cuda_stream)
+        sup = torch.zeros(200, dtype=torch.int32, device="cuda:0")
+        for _ in range(3):
+            c.step_phase(0, 0, 200, sup.data_ptr(), True)
+            c.step_phase(1, 0, 200, sup.data_ptr(), True)
+        c.sync()
+        part = c.fetch_results()
+    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+        assert part[k] == full[k]
+    assert np.array_equal(part["li"], full["li"]) and np.array_equal(part["hi"], full["hi"])
+    assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+    c.close()
+
+
 # --------------------------------------------------------------------------- edge cases / errors
 def test_no_matches_is_pass_through(hip, oracle_lib):
     fr = make_frame(L=12, H=10, seed=401)
