@@ -335,6 +335,48 @@ def test_invisible_features_and_ic_check(hip, oracle_lib):
     g.close()
 
 
+def test_not_spd_is_reported_not_fatal(hip):
+    """A covariance that is not positive definite must come back as RSLAM_ERR_NOT_SPD (the reference
+    would silently produce garbage; nothing may hang or abort)."""
+    fr = make_frame(L=20, H=16, seed=403)
+    g = hip.RslamHip(default_config(compat=0))
+    P = -10.0 * np.eye(fr.n)
+    _, vis, _ = g.predict(fr.types, fr.x_pred, P)
+    with pytest.raises(hip.RslamError) as e:
+        g.ransac_update(fr.z, fr.ic & vis, fr.draws)
+    assert e.value.code == -6
+    # the context stays usable
+    _, vis, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+    r = g.ransac_update(fr.z, fr.ic & vis, fr.draws)
+    assert r["best_support"] > 0
+    g.close()
+
+
+def test_more_than_1024_matched_features(hip, oracle_lib):
+    """m > 1024: the scoring workgroup loops over feature chunks; supports and masks bit-exact."""
+    fr = make_frame(L=1100, H=24, seed=404)
+    for compat in (1, 0):
+        cfg = default_config(compat=compat, adaptive=0)
+        o = oracle_lib.Oracle(cfg, structure=1)
+        _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
+        ic = (fr.ic & v0).astype(np.uint8)
+        assert ic.sum() > 1024
+        o.ransac_only(fr.z, ic, fr.draws)
+        sup0, _, masks0 = o.supports()
+        g = hip.RslamHip(cfg)
+        g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+        import torch
+        sup = torch.zeros(24, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        g.step_predict()
+        g.step_score(0, 24, sup.data_ptr())
+        g.sync()
+        _, masks1 = g.fetch_supports()
+        assert np.array_equal(sup.cpu().numpy(), sup0) and np.array_equal(masks1, masks0)
+        assert o.margins()[0] > 1e-9
+        g.close()
+
+
 def test_compat_cartesian_mismatch_returns_ref_assert(hip):
     fr = make_frame(L=9, H=4, seed=71, frac_cartesian=0.3)
     g = hip.RslamHip(default_config(compat=1))
