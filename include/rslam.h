@@ -137,6 +137,28 @@ int rslam_set_posterior (rslam_ctx* ctx, const rslam_layout* layout, const doubl
 int rslam_ekf_prediction(rslam_ctx* ctx, double delta_t, double std_a, double std_alpha);
 int rslam_fetch_prior   (rslam_ctx* ctx, double* x_pred /* host n, may be NULL */, double* P_pred /* host n*n, may be NULL */);
 
+/* Map::map_management's edits of x_k_k / p_k_k on the resident posterior, so
+ * that the covariance never leaves HBM between frames.  The host keeps features_info (patches,
+ * counters) and mirrors each call there; the context tracks the layout (rslam_get_layout).
+ *   rslam_map_delete_feature  Map::delete_a_feature (Map.cpp:69-104), feature index 0-based
+ *   rslam_map_convert         Map::inversedepth_2_cartesian (Map.cpp:105-196): the first inverse-depth
+ *                             feature whose linearity index is < threshold (0.1 in the reference) becomes
+ *                             Cartesian; *converted = its index or -1; linearity (L, may be NULL) receives
+ *                             every index (-1 for Cartesian features)
+ *   rslam_map_add_feature     ExtendKF::hinv (ExtendKF.cpp:236-265) + Map::add_a_feature_covariance_inverse_depth
+ *                             (Map.cpp:339-400) for the distorted pixel uvd[2]; initial_rho = std_rho = 1 in
+ *                             the reference (Map.cpp:217-218,384)
+ *   rslam_map_predict         ExtendKF::predict_camera_measurements(x_k_k) as Map::initialize_a_features uses it
+ *                             for its occupancy test (Map.cpp:221-229,252-261); h (L*2), visible (L)
+ * Each returns after the edit completed; follow with rslam_ekf_prediction and
+ * rslam_predict(ctx, &new_layout, NULL, NULL, ...). */
+int rslam_map_delete_feature(rslam_ctx* ctx, int32_t feature);
+int rslam_map_convert       (rslam_ctx* ctx, double linearity_threshold, int32_t* converted, double* linearity);
+int rslam_map_add_feature   (rslam_ctx* ctx, const double* uvd, double initial_rho, double std_rho);
+int rslam_map_predict       (rslam_ctx* ctx, double* h, uint8_t* visible);
+int rslam_get_layout        (rslam_ctx* ctx, int32_t* n, int32_t* L, uint8_t* type /* L, may be NULL */,
+                             int32_t* offset /* L, may be NULL */);
+
 int rslam_fetch_cov  (rslam_ctx* ctx, double* P /* host, n*n */);
 int rslam_fetch_state(rslam_ctx* ctx, double* x /* host, n   */);
 /* Per-stage hipEvent timing of eager (non-graph) frames: off by default. */

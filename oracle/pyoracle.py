@@ -63,6 +63,13 @@ def lib():
         L.orc_adaptive_n_hyp.argtypes = [C.c_double, C.c_int, C.c_int]
         L.orc_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.orc_inverse_lu.argtypes = [C.c_int, _dp, _dp]
+        L.orc_map_delete_feature.argtypes = [C.c_int, C.c_int, _u8p, _dp, _dp, C.c_int, _dp, _dp]
+        L.orc_map_convert.argtypes = [C.c_int, C.c_int, _u8p, _dp, _dp, C.c_double, _dp, _dp, C.POINTER(C.c_int)]
+        L.orc_linearity_index.argtypes = [_dp, _dp, C.c_int, C.c_int]
+        L.orc_linearity_index.restype = C.c_double
+        L.orc_map_add_feature.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]
+        L.orc_hinv.argtypes = [C.c_void_p, _dp, _dp, C.c_double, _dp]
+        L.orc_add_feature_jacobians.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
         L.orc_ekf_prediction.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         L.orc_motion_model.argtypes = [_dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]
         _lib = L
@@ -275,3 +282,58 @@ def motion_model(xv, delta_t=1.0, std_a=0.007, std_alpha=0.007):
     Q = np.zeros((13, 13), order="F")
     lib().orc_motion_model(_p(xv), delta_t, std_a, std_alpha, _p(xp), _p(F), _p(Q))
     return xp, F, Q
+
+
+def map_delete_feature(types, x, P, feature):
+    types = np.ascontiguousarray(types, np.uint8)
+    x = np.ascontiguousarray(x, np.float64); P = np.asfortranarray(P, np.float64)
+    n = len(x); w = 6 if types[feature] == 0 else 3
+    xo = np.zeros(n - w); Po = np.zeros((n - w, n - w), order="F")
+    rc = lib().orc_map_delete_feature(n, len(types), _p(types, _u8p), _p(x), _p(P), feature, _p(xo), _p(Po))
+    if rc:
+        raise OracleError(rc)
+    return xo, Po
+
+
+def map_convert(types, x, P, threshold=0.1):
+    types = np.ascontiguousarray(types, np.uint8)
+    x = np.ascontiguousarray(x, np.float64); P = np.asfortranarray(P, np.float64)
+    n = len(x)
+    xo = np.zeros(n - 3); Po = np.zeros((n - 3, n - 3), order="F")
+    conv = C.c_int(-1)
+    rc = lib().orc_map_convert(n, len(types), _p(types, _u8p), _p(x), _p(P), threshold, _p(xo), _p(Po), C.byref(conv))
+    if rc:
+        raise OracleError(rc)
+    if conv.value < 0:
+        return -1, x, P
+    return conv.value, xo, Po
+
+
+def linearity_index(x, P, offset):
+    x = np.ascontiguousarray(x, np.float64); P = np.asfortranarray(P, np.float64)
+    return lib().orc_linearity_index(_p(x), _p(P), len(x), offset)
+
+
+def map_add_feature(cam, std_z, x, P, uvd, initial_rho=1.0, std_rho=1.0):
+    x = np.ascontiguousarray(x, np.float64); P = np.asfortranarray(P, np.float64)
+    uvd = np.ascontiguousarray(uvd, np.float64)
+    n = len(x)
+    xo = np.zeros(n + 6); Po = np.zeros((n + 6, n + 6), order="F")
+    rc = lib().orc_map_add_feature(C.byref(cam), std_z, n, _p(x), _p(P), _p(uvd), initial_rho, std_rho, _p(xo), _p(Po))
+    if rc:
+        raise OracleError(rc)
+    return xo, Po
+
+
+def hinv(cam, uvd, Xv, initial_rho=1.0):
+    uvd = np.ascontiguousarray(uvd, np.float64); Xv = np.ascontiguousarray(Xv, np.float64)
+    y = np.zeros(6)
+    lib().orc_hinv(C.byref(cam), _p(uvd), _p(Xv), initial_rho, _p(y))
+    return y
+
+
+def add_feature_jacobians(cam, std_z, std_rho, uvd, Xv):
+    uvd = np.ascontiguousarray(uvd, np.float64); Xv = np.ascontiguousarray(Xv, np.float64)
+    D = np.zeros((6, 13), order="F"); Rn = np.zeros((6, 6), order="F")
+    lib().orc_add_feature_jacobians(C.byref(cam), std_z, std_rho, _p(uvd), _p(Xv), _p(D), _p(Rn))
+    return D, Rn

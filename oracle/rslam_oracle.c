@@ -1165,6 +1165,228 @@ int orc_ekf_prediction(int n, const double* x_kk, const double* P_kk, double del
 }
 
 /* ------------------------------------------------------------------ */
+/* Map state surgery: the x / P edits of Map.cpp       */
+/* ------------------------------------------------------------------ */
+
+static int feature_width(uint8_t t) { return t == RSLAM_FEAT_INVERSE_DEPTH ? 6 : 3; }
+static int feature_offset(const uint8_t* type, int i)
+{
+    int o = 13;
+    for (int k = 0; k < i; ++k) o += feature_width(type[k]);
+    return o;
+}
+
+/* Map::delete_a_feature, Map.cpp:69-104 (feature 0-based here).  Outputs sized n - width. */
+int orc_map_delete_feature(int n, int L, const uint8_t* type, const double* x, const double* P,
+                           int feature, double* x_out, double* P_out)
+{
+    if (feature < 0 || feature >= L) return RSLAM_ERR_ARG;
+    const int w = feature_width(type[feature]), o = feature_offset(type, feature), n2 = n - w;
+    for (int i = 0, i2 = 0; i < n; ++i) {
+        if (i >= o && i < o + w) continue;
+        x_out[i2] = x[i];
+        for (int j = 0, j2 = 0; j < n; ++j) {
+            if (j >= o && j < o + w) continue;
+            P_out[i2 + (size_t)j2 * n2] = P[i + (size_t)j * n];
+            ++j2;
+        }
+        ++i2;
+    }
+    return RSLAM_OK;
+}
+
+/* ExtendKF::inversedepth2cartesian, ExtendKF.cpp:137-152 */
+static void inversedepth2cartesian(const double y[6], double c[3])
+{
+    const double theta = y[3], phi = y[4], rho = y[5];
+    const double m[3] = { cos(phi) * sin(theta), -sin(phi), cos(phi) * cos(theta) };
+    for (int a = 0; a < 3; ++a) c[a] = y[a] + (1.0 / rho) * m[a];
+}
+
+/* linearity index of an inverse-depth feature, Map.cpp:124-149 */
+double orc_linearity_index(const double* x, const double* P, int n, int o)
+{
+    const double std_rho = sqrt(P[(o + 5) + (size_t)(o + 5) * n]);
+    const double rho = x[o + 5];
+    const double std_d = std_rho / (rho * rho);
+    double X_out[3];
+    inversedepth2cartesian(x + o, X_out);
+    double d1[3], d2[3];
+    for (int a = 0; a < 3; ++a) { d1[a] = X_out[a] - x[o + a]; d2[a] = X_out[a] - x[a]; }
+    const double d_c2p = sqrt(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2]);
+    const double aa = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+    const double bb = sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]) * d_c2p;
+    const double cos_alpha = aa / bb;
+    return 4 * std_d * cos_alpha / d_c2p;
+}
+
+/* Map::inversedepth_2_cartesian, Map.cpp:105-196: the first inverse-depth feature whose linearity
+ * index is below the threshold is converted (one per call); *converted = its index or -1.
+ * Outputs sized for n - 3 (untouched when nothing converts). */
+int orc_map_convert(int n, int L, const uint8_t* type, const double* x, const double* P, double threshold,
+                    double* x_out, double* P_out, int* converted)
+{
+    *converted = -1;
+    for (int i = 0; i < L; ++i) {
+        if (type[i] != RSLAM_FEAT_INVERSE_DEPTH) continue;
+        const int o = feature_offset(type, i);
+        if (!(orc_linearity_index(x, P, n, o) < threshold)) continue;
+        const int n2 = n - 3;
+        const double theta = x[o + 3], phi = x[o + 4], rho = x[o + 5];
+        const double mi[3] = { cos(phi) * sin(theta), -sin(phi), cos(phi) * cos(theta) };
+        const double dmt[3] = { cos(phi) * cos(theta), 0, -cos(phi) * sin(theta) };
+        const double dmp[3] = { -sin(phi) * sin(theta), -cos(phi), -sin(phi) * cos(theta) };
+        double J[18];   /* 3 x 6 col-major: [I3, dm_dtheta/rho, dm_dphi/rho, -mi/rho^2] */
+        memset(J, 0, sizeof(J));
+        for (int a = 0; a < 3; ++a) {
+            J[a + 3 * a] = 1.0;
+            J[a + 3 * 3] = (1 / rho) * dmt[a];
+            J[a + 3 * 4] = (1 / rho) * dmp[a];
+            J[a + 3 * 5] = -mi[a] / (rho * rho);
+        }
+        double X_out[3];
+        inversedepth2cartesian(x + o, X_out);
+        for (int k = 0; k < o; ++k) x_out[k] = x[k];
+        for (int a = 0; a < 3; ++a) x_out[o + a] = X_out[a];
+        for (int k = o + 6; k < n; ++k) x_out[k - 3] = x[k];
+        /* P_expansion = J_all * P * J_all' : tmp = J_all * P (n2 x n), then * J_all' */
+        double* tmp = (double*)malloc(sizeof(double) * (size_t)n2 * n);
+        for (int j = 0; j < n; ++j)
+            for (int i2 = 0; i2 < n2; ++i2) {
+                double v;
+                if (i2 < o) v = P[i2 + (size_t)j * n];
+                else if (i2 < o + 3) {
+                    v = 0;
+                    for (int k = 0; k < 6; ++k) v += J[(i2 - o) + 3 * k] * P[(o + k) + (size_t)j * n];
+                } else v = P[(i2 + 3) + (size_t)j * n];
+                tmp[i2 + (size_t)j * n2] = v;
+            }
+        for (int j2 = 0; j2 < n2; ++j2)
+            for (int i2 = 0; i2 < n2; ++i2) {
+                double v;
+                if (j2 < o) v = tmp[i2 + (size_t)j2 * n2];
+                else if (j2 < o + 3) {
+                    v = 0;
+                    for (int k = 0; k < 6; ++k) v += tmp[i2 + (size_t)(o + k) * n2] * J[(j2 - o) + 3 * k];
+                } else v = tmp[i2 + (size_t)(j2 + 3) * n2];
+                P_out[i2 + (size_t)j2 * n2] = v;
+            }
+        free(tmp);
+        *converted = i;
+        return RSLAM_OK;      /* "only convert one feature per step", Map.cpp:192 */
+    }
+    return RSLAM_OK;
+}
+
+/* ExtendKF::hinv, ExtendKF.cpp:236-265 (cam->K(0,0) = K(1,1) = f/d with d = dx = dy, System.cpp:57) */
+void orc_hinv(const rslam_camera* cam, const double uvd[2], const double Xv[13], double initial_rho, double y[6])
+{
+    const double fku = cam->f / cam->dx, fkv = cam->f / cam->dy, U0 = cam->Cx, V0 = cam->Cy;
+    double uv[2];
+    orc_undistort_fm(cam, uvd, uv);
+    const double hx = -(U0 - uv[0]) / fku, hy = -(V0 - uv[1]) / fkv, hz = 1;
+    double R[9];
+    orc_q2r(Xv + 3, R);
+    const double nx = R[0] * hx + R[3] * hy + R[6] * hz;
+    const double ny = R[1] * hx + R[4] * hy + R[7] * hz;
+    const double nz = R[2] * hx + R[5] * hy + R[8] * hz;
+    y[0] = Xv[0]; y[1] = Xv[1]; y[2] = Xv[2];
+    y[3] = atan2(nx, nz);
+    y[4] = atan2(-ny, sqrt(nx * nx + nz * nz));
+    y[5] = initial_rho;
+}
+
+/* dy_dxv (6 x 13) and dy_dhd * Padd * dy_dhd' (6 x 6) of Map::add_a_feature_covariance_inverse_depth,
+ * Map.cpp:339-388, both col-major; std_rho = 1 in the reference (Map.cpp:218,384). */
+void orc_add_feature_jacobians(const rslam_camera* cam, double std_z, double std_rho, const double uvd[2],
+                               const double Xv[13], double D[78], double Rn[36])
+{
+    const double fku = cam->f / cam->dx, fkv = cam->f / cam->dy, U0 = cam->Cx, V0 = cam->Cy;
+    const double* q = Xv + 3;
+    double R[9], uvu[2];
+    orc_q2r(q, R);
+    orc_undistort_fm(cam, uvd, uvu);
+    const double c[3] = { -(U0 - uvu[0]) / fku, -(V0 - uvu[1]) / fkv, 1 };
+    const double Xw = R[0] * c[0] + R[3] * c[1] + R[6] * c[2];
+    const double Yw = R[1] * c[0] + R[4] * c[1] + R[7] * c[2];
+    const double Zw = R[2] * c[0] + R[5] * c[1] + R[8] * c[2];
+    double dgw_dq[12];
+    orc_dRq_times_a_by_dq(q, c, dgw_dq);
+    const double xz = Xw * Xw + Zw * Zw, xyz = Xw * Xw + Yw * Yw + Zw * Zw;
+    const double dth[3] = { Zw / xz, 0, -Xw / xz };
+    const double dph[3] = { (Xw * Yw) / (xyz * sqrt(xz)), -sqrt(xz) / xyz, (Zw * Yw) / (xyz * sqrt(xz)) };
+    memset(D, 0, sizeof(double) * 78);
+    for (int a = 0; a < 3; ++a) D[a + 6 * a] = 1.0;                 /* dy_drw = [I3; 0] */
+    for (int k = 0; k < 4; ++k) {                                    /* dy_dqwr rows 3, 4 */
+        double s3 = 0, s4 = 0;
+        for (int a = 0; a < 3; ++a) { s3 += dth[a] * dgw_dq[a + 3 * k]; s4 += dph[a] * dgw_dq[a + 3 * k]; }
+        D[3 + 6 * (3 + k)] = s3; D[4 + 6 * (3 + k)] = s4;
+    }
+    /* dyprima_dhd = dyprima_dgw * R_wc * dgc_dhu * dhu_dhd  (5 x 2), rows 3,4 non-zero */
+    double Jd[4];
+    orc_jacob_undistor_fm(cam, uvd, Jd);
+    double A32[6];   /* R_wc * dgc_dhu : 3 x 2 col-major */
+    for (int a = 0; a < 3; ++a) { A32[a] = R[a] * (1 / fku); A32[a + 3] = R[a + 3] * (1 / fkv); }
+    double B32[6];   /* (R dgc_dhu) * dhu_dhd */
+    for (int a = 0; a < 3; ++a)
+        for (int j = 0; j < 2; ++j) B32[a + 3 * j] = A32[a] * Jd[0 + 2 * j] + A32[a + 3] * Jd[1 + 2 * j];
+    double E[18];    /* dy_dhd : 6 x 3 col-major */
+    memset(E, 0, sizeof(E));
+    for (int j = 0; j < 2; ++j) {
+        double s3 = 0, s4 = 0;
+        for (int a = 0; a < 3; ++a) { s3 += dth[a] * B32[a + 3 * j]; s4 += dph[a] * B32[a + 3 * j]; }
+        E[3 + 6 * j] = s3; E[4 + 6 * j] = s4;
+    }
+    E[5 + 6 * 2] = 1.0;
+    const double padd[3] = { pow(std_z, 2), pow(std_z, 2), pow(std_rho, 2) };
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double sacc = 0;
+            for (int k = 0; k < 3; ++k) sacc += (E[i + 6 * k] * padd[k]) * E[j + 6 * k];
+            Rn[i + 6 * j] = sacc;
+        }
+}
+
+/* Map::initialize_a_features lines 281-292 with Map::add_a_feature_covariance_inverse_depth
+ * (Map.cpp:339-400): append one inverse-depth feature observed at the distorted pixel uvd.
+ * Outputs sized n + 6. */
+int orc_map_add_feature(const rslam_camera* cam, double std_z, int n, const double* x, const double* P,
+                        const double uvd[2], double initial_rho, double std_rho, double* x_out, double* P_out)
+{
+    const int n2 = n + 6;
+    double y[6], D[78], Rn[36];
+    orc_hinv(cam, uvd, x, initial_rho, y);
+    orc_add_feature_jacobians(cam, std_z, std_rho, uvd, x, D, Rn);
+    memcpy(x_out, x, sizeof(double) * n);
+    memcpy(x_out + n, y, sizeof(double) * 6);
+    for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < n; ++i) P_out[i + (size_t)j * n2] = P[i + (size_t)j * n];
+        for (int a = 0; a < 6; ++a) {                  /* dy_dxv * P(0:13, :) */
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) sacc += D[a + 6 * k] * P[k + (size_t)j * n];
+            P_out[(n + a) + (size_t)j * n2] = sacc;
+        }
+    }
+    for (int b = 0; b < 6; ++b) {
+        for (int i = 0; i < n; ++i) {                  /* P(:, 0:13) * dy_dxv' */
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) sacc += P[i + (size_t)k * n] * D[b + 6 * k];
+            P_out[i + (size_t)(n + b) * n2] = sacc;
+        }
+        for (int a = 0; a < 6; ++a) {                  /* (dy_dxv * P_xv) * dy_dxv' + dy_dhd Padd dy_dhd' */
+            double sacc = 0;
+            for (int k = 0; k < 13; ++k) {
+                double dp = 0;
+                for (int mm = 0; mm < 13; ++mm) dp += D[a + 6 * mm] * P[mm + (size_t)k * n];
+                sacc += dp * D[b + 6 * k];
+            }
+            P_out[(n + a) + (size_t)(n + b) * n2] = sacc + Rn[a + 6 * b];
+        }
+    }
+    return RSLAM_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* introspection                                                        */
 /* ------------------------------------------------------------------ */
 

@@ -90,6 +90,19 @@ int  orc_ekf_prediction(int n, const double* x_kk, const double* P_kk, double de
 /* its 13-state motion model: fv (:389-400), dfv_by_dxv (:444-465), Q = G Pn G' (:347-376) */
 void orc_motion_model(const double xv[13], double delta_t, double std_a, double std_alpha,
                       double xv_pred[13], double F[169], double Q[169]);
+/* Map state surgery; outputs sized for the new state dimension */
+int  orc_map_delete_feature(int n, int L, const uint8_t* type, const double* x, const double* P,
+                            int feature, double* x_out, double* P_out);                    /* Map.cpp:69-104  */
+int  orc_map_convert(int n, int L, const uint8_t* type, const double* x, const double* P, double threshold,
+                     double* x_out, double* P_out, int* converted);                         /* Map.cpp:105-196 */
+double orc_linearity_index(const double* x, const double* P, int n, int offset);            /* Map.cpp:124-149 */
+int  orc_map_add_feature(const rslam_camera* cam, double std_z, int n, const double* x, const double* P,
+                         const double uvd[2], double initial_rho, double std_rho,
+                         double* x_out, double* P_out);                                     /* Map.cpp:281-292,339-400 */
+void orc_hinv(const rslam_camera* cam, const double uvd[2], const double Xv[13], double initial_rho,
+              double y[6]);                                                                 /* ExtendKF.cpp:236-265 */
+void orc_add_feature_jacobians(const rslam_camera* cam, double std_z, double std_rho, const double uvd[2],
+                               const double Xv[13], double D[78], double Rn[36]);           /* Map.cpp:339-388 */
 /* dynamic-size inverse as Eigen does it (PartialPivLU), Tracking.cpp:421 */
 int  orc_inverse_lu(int n, const double* A, double* Ainv);
 

@@ -31,6 +31,11 @@ SYMBOLS = {
     "rslam_set_posterior": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp]),
     "rslam_ekf_prediction": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "rslam_fetch_prior": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "rslam_map_delete_feature": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rslam_map_convert": (C.c_int, [C.c_void_p, C.c_double, _i32p, _dp]),
+    "rslam_map_add_feature": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
+    "rslam_map_predict": (C.c_int, [C.c_void_p, _dp, _u8p]),
+    "rslam_get_layout": (C.c_int, [C.c_void_p, _i32p, _i32p, _u8p, _i32p]),
     "rslam_fetch_cov": (C.c_int, [C.c_void_p, _dp]),
     "rslam_fetch_state": (C.c_int, [C.c_void_p, _dp]),
     "rslam_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -142,6 +147,47 @@ class RslamHip:
 
     def ekf_prediction(self, delta_t=1.0, std_a=0.007, std_alpha=0.007):
         _chk(lib().rslam_ekf_prediction(self._h, delta_t, std_a, std_alpha), "rslam_ekf_prediction")
+
+    # ---- Map::map_management state surgery on the resident posterior -------
+    def get_layout(self):
+        n, L = C.c_int32(), C.c_int32()
+        _chk(lib().rslam_get_layout(self._h, C.byref(n), C.byref(L), None, None), "rslam_get_layout")
+        types = np.zeros(max(L.value, 1), np.uint8)
+        offs = np.zeros(max(L.value, 1), np.int32)
+        _chk(lib().rslam_get_layout(self._h, C.byref(n), C.byref(L), _p(types, _u8p), _p(offs, _i32p)), "rslam_get_layout")
+        self.n, self.L = n.value, L.value
+        return n.value, types[:L.value].copy(), offs[:L.value].copy()
+
+    def map_delete_feature(self, feature):
+        _chk(lib().rslam_map_delete_feature(self._h, int(feature)), "rslam_map_delete_feature")
+        self.get_layout()
+
+    def map_convert(self, threshold=0.1):
+        """-> (converted feature index or -1, linearity index of every feature)"""
+        conv = C.c_int32(-1)
+        lin = np.zeros(max(self.L, 1))
+        _chk(lib().rslam_map_convert(self._h, threshold, C.byref(conv), _p(lin)), "rslam_map_convert")
+        L_before = self.L
+        self.get_layout()
+        return conv.value, lin[:L_before]
+
+    def map_add_feature(self, uvd, initial_rho=1.0, std_rho=1.0):
+        uvd = np.ascontiguousarray(uvd, dtype=np.float64)
+        _chk(lib().rslam_map_add_feature(self._h, _p(uvd), initial_rho, std_rho), "rslam_map_add_feature")
+        self.get_layout()
+
+    def map_predict(self):
+        h = np.full((max(self.L, 1), 2), np.nan)
+        vis = np.zeros(max(self.L, 1), np.uint8)
+        _chk(lib().rslam_map_predict(self._h, _p(h), _p(vis, _u8p)), "rslam_map_predict")
+        return h[:self.L], vis[:self.L]
+
+    def fetch_posterior(self):
+        x = np.zeros(self.n)
+        P = np.zeros((self.n, self.n), order="F")
+        _chk(lib().rslam_fetch_state(self._h, _p(x)), "rslam_fetch_state")
+        _chk(lib().rslam_fetch_cov(self._h, _p(P)), "rslam_fetch_cov")
+        return x, P
 
     def fetch_prior(self):
         x = np.zeros(self.n)

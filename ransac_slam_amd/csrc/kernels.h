@@ -83,6 +83,15 @@ void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_
 // x[13:] and P beforehand
 void launch_ekf_prediction(hipStream_t s, int n, int NP, const double* x_kk, const double* P_kk, double dt,
                            double std_a, double std_alpha, double* x_pred, double* P_pred, double* FQ);
+// map_kernels.hip: Map::map_management state surgery on the resident posterior
+constexpr int MAP_COEF_DOUBLES = 160;
+void launch_map_state(hipStream_t s, int mode, const Cam& cam, const double* x_old, int o, double ud, double vd,
+                      double rho0, double std_z, double std_rho, double* coef, double* x_new, int n_new, int NP_new,
+                      int cut, int special, int shift);
+void launch_map_cov(hipStream_t s, const double* P, int ld_old, double* Pn, int ld_new, int n_new, int cut, int special,
+                    int shift, int sp_base, int sp_cnt, int add_r, const double* coef);
+void launch_map_linearity(hipStream_t s, const double* x, const double* P, int NP, int L, const uint8_t* type,
+                          const int32_t* off, double threshold, double* out, int32_t* first);
 int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kernels (80 KiB)
 int init_kernel_attributes2();
 void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,

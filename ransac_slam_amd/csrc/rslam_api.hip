@@ -73,7 +73,8 @@ struct rslam_ctx {
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Linv,
-                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ;
+                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin;
+    DevBuf<int32_t> d_first;
     // timing
     int timing = 0;
     hipEvent_t ev[EV_COUNT];
@@ -165,6 +166,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_H13b.release(); c->d_S.release(); c->d_S2.release(); c->d_z.release(); c->d_wv.release();
     c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
+    c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -613,6 +615,139 @@ extern "C" int rslam_ekf_prediction(rslam_ctx* c, double delta_t, double std_a, 
     return RSLAM_OK;
 }
 
+// ------------------------------------------------------------------------
+// Map::map_management state surgery on the resident posterior
+// ------------------------------------------------------------------------
+namespace {
+
+// a frame whose update stage is still in flight must have completed (and possibly been re-run,
+// see read_status) before its posterior is edited
+int settle_posterior(rslam_ctx* c)
+{
+    if (!c->have_post) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->have_meas && c->last_sup) {
+        const int st = read_status(c, nullptr);
+        if (st < 0) return st;
+    }
+    return RSLAM_OK;
+}
+
+// Runs the congruence into the scratch pair (d_xpred, d_Ppred), swaps it with the posterior
+// pair and installs the new layout.  mode 0 delete / 1 convert / 2 insert.
+int apply_map_edit(rslam_ctx* c, int mode, int cut, int special, int shift, int sp_base, int sp_cnt,
+                   const std::vector<uint8_t>& type, int o, double ud, double vd, double rho0, double std_rho)
+{
+    const int L2 = (int)type.size();
+    std::vector<int32_t> off((size_t)L2);
+    int n2 = 13;
+    for (int i = 0; i < L2; ++i) { off[i] = n2; n2 += type[i] == RSLAM_FEAT_INVERSE_DEPTH ? 6 : 3; }
+    const int NP2 = round_up(n2, 64);
+    if (c->d_xpred.ensure(NP2) < 0 || c->d_Ppred.ensure((size_t)NP2 * NP2) < 0 || c->d_mapcoef.ensure(MAP_COEF_DOUBLES) < 0)
+        return RSLAM_ERR_HIP;
+    hipStream_t s = c->stream;
+    launch_map_state(s, mode, c->cam, c->d_x2.p, o, ud, vd, rho0, c->cfg.sigma_z, std_rho, c->d_mapcoef.p, c->d_xpred.p,
+                     n2, NP2, cut, special, shift);
+    launch_map_cov(s, c->d_P.p, c->NP, c->d_Ppred.p, NP2, n2, cut, special, shift, sp_base, sp_cnt, mode == 2, c->d_mapcoef.p);
+    HIPCHK(hipGetLastError());
+    std::swap(c->d_x2, c->d_xpred);
+    std::swap(c->d_P, c->d_Ppred);
+    invalidate_graph(c);                       // the captured launches hold the old pointers
+    rslam_layout lay{n2, L2, type.data(), off.data()};
+    const int rc = set_layout(c, &lay);        // (d_x2, d_P) are large enough: never reallocated here
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    c->have_post = true; c->have_state = false; c->have_meas = false; c->predicted = false;
+    c->pht_done = false; c->dedup_done = false; c->last_sup = nullptr;
+    return RSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" int rslam_get_layout(rslam_ctx* c, int32_t* n, int32_t* L, uint8_t* type, int32_t* offset)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (n) *n = c->n;
+    if (L) *L = c->L;
+    for (int i = 0; i < c->L; ++i) {
+        if (type) type[i] = c->h_type[i];
+        if (offset) offset[i] = c->h_off[i];
+    }
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_map_delete_feature(rslam_ctx* c, int32_t feature)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    int rc = settle_posterior(c);
+    if (rc) return rc;
+    if (feature < 0 || feature >= c->L) return RSLAM_ERR_ARG;
+    const int w = c->h_type[feature] == RSLAM_FEAT_INVERSE_DEPTH ? 6 : 3;
+    std::vector<uint8_t> type(c->h_type);
+    type.erase(type.begin() + feature);
+    return apply_map_edit(c, 0, c->h_off[feature], 0, w, 0, 0, type, 0, 0.0, 0.0, 0.0, 0.0);
+}
+
+extern "C" int rslam_map_convert(rslam_ctx* c, double linearity_threshold, int32_t* converted, double* linearity)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (converted) *converted = -1;
+    int rc = settle_posterior(c);
+    if (rc) return rc;
+    const int L = c->L;
+    if (L == 0) return RSLAM_OK;
+    if (c->d_lin.ensure(L) < 0 || c->d_first.ensure(1) < 0) return RSLAM_ERR_HIP;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemsetAsync(c->d_first.p, 0x7f, sizeof(int32_t), s));
+    launch_map_linearity(s, c->d_x2.p, c->d_P.p, c->NP, L, c->d_type.p, c->d_off.p, linearity_threshold, c->d_lin.p, c->d_first.p);
+    HIPCHK(hipGetLastError());
+    int32_t first = 0;
+    HIPCHK(hipMemcpyAsync(&first, c->d_first.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (linearity) HIPCHK(hipMemcpyAsync(linearity, c->d_lin.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (first < 0 || first >= L) return RSLAM_OK;            // nothing below the threshold
+    std::vector<uint8_t> type(c->h_type);
+    type[first] = RSLAM_FEAT_CARTESIAN;
+    const int o = c->h_off[first];
+    rc = apply_map_edit(c, 1, o, 3, 3, o, 6, type, o, 0.0, 0.0, 0.0, 0.0);
+    if (rc) return rc;
+    if (converted) *converted = first;                        // one feature per call, Map.cpp:192
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_map_add_feature(rslam_ctx* c, const double* uvd, double initial_rho, double std_rho)
+{
+    if (!c || !uvd) return RSLAM_ERR_ARG;
+    int rc = settle_posterior(c);
+    if (rc) return rc;
+    std::vector<uint8_t> type(c->h_type);
+    type.push_back(RSLAM_FEAT_INVERSE_DEPTH);
+    return apply_map_edit(c, 2, c->n, 6, 0, 0, 13, type, 0, uvd[0], uvd[1], initial_rho, std_rho);
+}
+
+extern "C" int rslam_map_predict(rslam_ctx* c, double* h, uint8_t* visible)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    int rc = settle_posterior(c);
+    if (rc) return rc;
+    const int L = c->L;
+    if (L == 0) return RSLAM_OK;
+    hipStream_t s = c->stream;
+    // predict_camera_measurements(x_k_k), Map.cpp:221; h was reset at Map.cpp:51, so no stale values
+    launch_predict(s, c->cam, c->d_x2.p, c->d_P.p, c->NP, L, c->d_type.p, c->d_off.p, nullptr, nullptr,
+                   c->d_h2.p, c->d_hash2.p, c->d_vis.p, c->d_H13b.p, c->d_S2.p, 0.0, nullptr);
+    HIPCHK(hipGetLastError());
+    std::vector<double> hh(2 * (size_t)L);
+    HIPCHK(hipMemcpyAsync(hh.data(), c->d_h2.p, sizeof(double) * 2 * L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->h_vis.data(), c->d_vis.p, L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < L; ++i) {
+        if (visible) visible[i] = c->h_vis[i];
+        if (h && c->h_vis[i]) { h[2 * i] = hh[2 * i]; h[2 * i + 1] = hh[2 * i + 1]; }
+    }
+    return RSLAM_OK;
+}
+
 extern "C" int rslam_fetch_prior(rslam_ctx* c, double* x_pred, double* P_pred)
 {
     if (!c) return RSLAM_ERR_ARG;
@@ -628,7 +763,7 @@ extern "C" int rslam_fetch_prior(rslam_ctx* c, double* x_pred, double* P_pred)
 extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
 {
     if (!c || !P) return RSLAM_ERR_ARG;
-    if (!c->have_state) return RSLAM_ERR_STATE;
+    if (!c->have_state && !c->have_post) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy2DAsync(P, sizeof(double) * c->n, c->d_P.p, sizeof(double) * c->NP, sizeof(double) * c->n, c->n,
                             hipMemcpyDeviceToHost, c->stream));
@@ -639,7 +774,7 @@ extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
 extern "C" int rslam_fetch_state(rslam_ctx* c, double* x)
 {
     if (!c || !x) return RSLAM_ERR_ARG;
-    if (!c->have_state) return RSLAM_ERR_STATE;
+    if (!c->have_state && !c->have_post) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(x, c->d_x2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

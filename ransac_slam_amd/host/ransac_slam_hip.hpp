@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/rslam.h"
@@ -209,6 +210,62 @@ private:
     ExtendKF* mT_ExtendKF;
     std::vector<uint8_t> type_, li_, hi_;
     std::vector<int32_t> offset_;
+};
+
+// Map methods that edit the filter state (Map.h:24-37), run on the posterior that the update
+// left in HBM: with these, System::TrackRunning never moves p_k_k across PCIe
+// (ExtendKF::ekf_prediction(false, ...) follows).  Image work -- FAST corners, patches, the
+// random box of Map::initialize_a_features (Map.cpp:232-250) -- stays on the host.
+class Map {
+public:
+    explicit Map(ExtendKF* m_ExtendKF) : mM_ExtendKF(m_ExtendKF) {}
+
+    // Map::delete_a_feature (Map.cpp:69-104); featToDelete counts from 1 as in Map.cpp:21.  The caller
+    // erased features_info[featToDelete - 1] beforehand, as Map::map_management does (Map.cpp:27-28).
+    void delete_a_feature(int featToDelete)
+    {
+        const int rc = rslam_map_delete_feature(mM_ExtendKF->ctx(), featToDelete - 1);
+        if (rc) throw Error(rc, "rslam_map_delete_feature");
+    }
+
+    // Map::inversedepth_2_cartesian (Map.cpp:105-196): at most one feature per call
+    int inversedepth_2_cartesian(double linearity_index_threshold = 0.1)
+    {
+        int32_t converted = -1;
+        const int rc = rslam_map_convert(mM_ExtendKF->ctx(), linearity_index_threshold, &converted, nullptr);
+        if (rc) throw Error(rc, "rslam_map_convert");
+        if (converted >= 0) mM_ExtendKF->features_info[converted].type = "cartesian";     // Map.cpp:191
+        return converted;
+    }
+
+    // First step of Map::initialize_a_features (Map.cpp:221-229): where every feature is expected,
+    // for the occupancy test of the sampling box (Map.cpp:252-261)
+    std::vector<std::array<double, 2>> predicted_positions()
+    {
+        ExtendKF& k = *mM_ExtendKF;
+        const int L = (int)k.features_info.size();
+        std::vector<double> h(2 * (size_t)L + 1);
+        std::vector<uint8_t> vis((size_t)L + 1);
+        const int rc = rslam_map_predict(k.ctx(), h.data(), vis.data());
+        if (rc) throw Error(rc, "rslam_map_predict");
+        std::vector<std::array<double, 2>> h_pred;
+        for (int i = 0; i < L; ++i) if (vis[i]) h_pred.push_back({h[2 * i], h[2 * i + 1]});
+        return h_pred;
+    }
+
+    // Fourth step of Map::initialize_a_features (Map.cpp:271-312): hinv, the covariance of the new
+    // feature (add_a_feature_covariance_inverse_depth, Map.cpp:339-400) and its features_info entry
+    void add_a_feature(const double uv[2], int initial_rho = 1, int std_rho = 1)
+    {
+        const int rc = rslam_map_add_feature(mM_ExtendKF->ctx(), uv, initial_rho, std_rho);
+        if (rc) throw Error(rc, "rslam_map_add_feature");
+        Feature f;
+        f.type = "inversedepth";
+        mM_ExtendKF->features_info.push_back(f);
+    }
+
+private:
+    ExtendKF* mM_ExtendKF;
 };
 
 }  // namespace ransac_slam_hip

@@ -1,7 +1,9 @@
 // track_frame_example.cpp -- the five hot calls of System::TrackRunning (System.cpp:117-129)
 // driven through the host-side mirror (ransac_slam_hip.hpp).  Reads a frame dumped by
 // tests/test_host_adapter.py, writes the outputs; the test compares them with the oracle.
-//   usage: track_frame_example frame.bin out.bin
+//   usage: track_frame_example frame.bin out.bin [map.bin]
+// With a third argument the map management of the next frame follows on the device (Map mirror):
+// delete, convert, insert, then ExtendKF::ekf_prediction with nothing uploaded.
 #include <cstdio>
 #include <cstring>
 
@@ -62,6 +64,34 @@ int main(int argc, char** argv)
         fwrite(kf.x_k_k.data(), sizeof(double), n, o);
         fwrite(kf.p_k_k.data(), sizeof(double), (size_t)n * n, o);
         fclose(o);
+
+        if (argc > 3) {                                              // System.cpp:111-114 of the next frame
+            Map map(&kf);
+            kf.features_info.erase(kf.features_info.begin() + 2);   // Map.cpp:27-28
+            map.delete_a_feature(3);
+            const int converted = map.inversedepth_2_cartesian(1e-30);   // nothing is that linear: no edit
+            const size_t visible = map.predicted_positions().size();
+            const double uv[2] = {140.0, 100.0};
+            map.add_a_feature(uv);
+            std::vector<uint8_t> t2; std::vector<int32_t> o2;
+            int off = 13;
+            for (const Feature& ft : kf.features_info) {
+                const bool id = ft.type == "inversedepth";
+                t2.push_back(id ? 0 : 1); o2.push_back(off); off += id ? 6 : 3;
+            }
+            kf.ekf_prediction(false, t2, o2);
+            std::vector<double> xp(off), Pp((size_t)off * off);
+            const int rc = rslam_fetch_prior(kf.ctx(), xp.data(), Pp.data());
+            if (rc) throw Error(rc, "rslam_fetch_prior");
+            FILE* m = fopen(argv[3], "wb");
+            if (!m) { perror("map"); return 2; }
+            int32_t mh[4] = {off, (int32_t)t2.size(), converted, (int32_t)visible};
+            fwrite(mh, sizeof(int32_t), 4, m);
+            fwrite(t2.data(), 1, t2.size(), m);
+            fwrite(xp.data(), sizeof(double), xp.size(), m);
+            fwrite(Pp.data(), sizeof(double), Pp.size(), m);
+            fclose(m);
+        }
     } catch (const Error& e) {
         fprintf(stderr, "error %d: %s\n", e.code, e.what());
         return 1;
