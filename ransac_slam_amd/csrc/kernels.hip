@@ -542,230 +542,403 @@ __device__ __forceinline__ double rsqrt_f64(double d)
     return y;
 }
 
-// ---- 64 x 64 diagonal block: Cholesky factor and its inverse, 4 pivots per step -------
-// The serial pivot chain is what bounds the whole sweep, so it is cut four-fold: one step
-// eliminates a 4 x 4 pivot block.
-//   A  every lane computes the 4 x 4 Cholesky factor of the pivot block in closed form
-//      (10 broadcast LDS reads, 4 reciprocal square roots);
-//   B  64 lanes solve their row of the 64 x 4 panel X = A(:,p) L4^-T, 64 lanes their column
-//      of the pivot rows of the running inverse, L4^-1 M(p,:), by 4-step substitution;
-//   C  the trailing matrix and the running inverse live in MFMA accumulator tiles
-//      (16 x 16, ten lower tiles each, spread over the 4 waves); a rank-4 update of a tile
-//      is exactly ONE v_mfma_f64_16x16x4_f64 (K = 4) with operands read from the panel;
-//   D  the owners publish the next pivot's 4 columns / 4 inverse rows to LDS.
-// Two barriers per 4 pivots; L and L^-1 are collected in LDS and written once at the end
-// (a global store inside the loop would put a vmcnt(0) wait into every barrier).
+// ---- 64 x 64 diagonal block: Cholesky factor and its inverse ---------------------------
+// The serial pivot chain of these blocks bounds the whole sweep.  It is cut four-fold (one
+// iteration eliminates a 4 x 4 pivot block) and software-pipelined across the ten waves of one
+// workgroup so that only what the NEXT pivot block needs sits on the chain.  Measured on
+// MI355X: a wave64 instruction costs ~4-5 cycles of its SIMD whatever it is (FP64 FMA, select,
+// address arithmetic; dependent or not), an LDS round trip ~100, v_rsq_f64 ~20 -- so the chain
+// is bound by the NUMBER of instructions the panel wave executes per pivot block, and everything
+// that is not strictly needed for the next pivot lives in other waves:
+//   wave 0 (panel wave, lane = row)   reads the 4 columns of pivot block s ("strip", one update
+//          behind), applies the rank-4 update of block s-1 to them itself and runs a
+//          lane-parallel right-looking Cholesky over the 4 columns: the pivot-row lanes end up
+//          holding L4, the other lanes their row of the panel X = T(:,p) L4^-T; L4 entries and
+//          pivots travel by readlane.  ~110 instructions per block.
+//   wave 1 (inverse wave, lane = column) follows one block behind: rows p of the running
+//          inverse, Ms = L4^-1 M(p,:), with L4 read from the panel and the pivot reciprocals
+//          published by wave 0;
+//   waves 2..6 (T waves) hold the trailing matrix in MFMA accumulator tiles (16 x 16, the ten
+//          lower tiles, two per wave); in iteration s they apply T -= X(s-1) X(s-1)^T (ONE
+//          v_mfma_f64_16x16x4_f64 per tile) and publish the strip of block s+1;
+//   waves 7..9 (M waves) hold the running inverse the same way and apply M -= X(s-2) Ms(s-2).
+// Rows at and above the current pivot carry don't-care values in X (they only reach tile
+// entries that are never read again), so nothing is masked.  No barrier inside the chain:
+// panels and strips are multi-buffered in LDS and handed over through LDS flags (producer:
+// data, release fence, flag; consumer: poll, acquire fence).  L and L^-1 are collected in LDS
+// and written once at the end (a global store inside the loop would put a vmcnt(0) wait on
+// the chain).
 constexpr int CD_LD = 65;
+constexpr int CD_TW = 5;            // T waves
+constexpr int CD_MW = 3;            // M waves
+constexpr int CD_THREADS = 64 * (2 + CD_TW + CD_MW);
+constexpr int CD_SPIN_LIMIT = 1 << 20;
 
-struct Chol4 { double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3; bool bad; };
+struct CdShared {
+    double Lf[64 * CD_LD];       // L, column-major
+    double Mf[64 * CD_LD];       // L^-1, column-major
+    double Xs[4][4 * 64];        // [k][row]: panel of block s (buffer s & 3)
+    double Ms[2][4 * 64];        // [k][col]: L4^-1 M(p,:) of block s (buffer s & 1)
+    double Tst[2][4 * 64];       // [k][row]: columns of pivot block s (buffer s & 1), updates <= s-2 applied
+    double Mst[2][4 * 64];       // [k][col]: rows of pivot block s of the running inverse (buffer s & 1), updates <= s-2
+    double Rs[2][4];             // reciprocal square roots of the pivots of block s (buffer s & 1)
+    int flags[16];               // 0: blocks finished by the panel wave; 1: by the inverse wave; 2..6: iterations of T wave; 7..9: of M wave
+    int timeout;
+};
 
 #if defined(CD_STAMPS)   // diagnostic build: where do the cycles of a pivot step go (never in the product build)
 __device__ unsigned long long g_cd_stamps[8];
 #define CD_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define CD_ACC(slot, a, b) do { if (t == 0) g_cd_stamps[slot] += (b) - (a); } while (0)
+#define CD_ACC_T(slot, a, b, tid) do { if (threadIdx.x == (tid)) g_cd_stamps[slot] += (b) - (a); } while (0)
+#define CD_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #else
 #define CD_STAMP(var)
-#define CD_ACC(slot, a, b)
+#define CD_ACC_T(slot, a, b, tid)
+#define CD_PIN4(a, b, c, d)
 #endif
 
-__device__ __forceinline__ Chol4 chol4(const double* Tc /* [4][64] */, int p0)
+// wait until panel flag >= need_panel, inverse flag >= need_inv, every T-wave flag >= need_t and
+// every M-wave flag >= need_m; wave-uniform, bounded so that a logic error ends in an error
+// code instead of a hung queue
+template <int SLEEP>
+__device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_inv, int need_t, int need_m)
 {
-    const double d00 = Tc[0 * 64 + p0], d10 = Tc[0 * 64 + p0 + 1], d20 = Tc[0 * 64 + p0 + 2], d30 = Tc[0 * 64 + p0 + 3];
-    const double d11 = Tc[1 * 64 + p0 + 1], d21 = Tc[1 * 64 + p0 + 2], d31 = Tc[1 * 64 + p0 + 3];
-    const double d22 = Tc[2 * 64 + p0 + 2], d32 = Tc[2 * 64 + p0 + 3], d33 = Tc[3 * 64 + p0 + 3];
-    Chol4 c;
-    c.bad = !(d00 > 0.0);
-    c.r0 = rsqrt_f64(d00);
-    c.l10 = d10 * c.r0; c.l20 = d20 * c.r0; c.l30 = d30 * c.r0;
-    const double t11 = fma(-c.l10, c.l10, d11);
-    c.bad = c.bad || !(t11 > 0.0);
-    c.r1 = rsqrt_f64(t11);
-    c.l21 = fma(-c.l20, c.l10, d21) * c.r1;
-    c.l31 = fma(-c.l30, c.l10, d31) * c.r1;
-    const double t22 = fma(-c.l21, c.l21, fma(-c.l20, c.l20, d22));
-    c.bad = c.bad || !(t22 > 0.0);
-    c.r2 = rsqrt_f64(t22);
-    c.l32 = fma(-c.l31, c.l21, fma(-c.l30, c.l20, d32)) * c.r2;
-    const double t33 = fma(-c.l32, c.l32, fma(-c.l31, c.l31, fma(-c.l30, c.l30, d33)));
-    c.bad = c.bad || !(t33 > 0.0);
-    c.r3 = rsqrt_f64(t33);
-    return c;
+    const int li = threadIdx.x & 15;
+    const int need = li == 0 ? need_panel : li == 1 ? need_inv : li < 2 + CD_TW ? need_t : li < 2 + CD_TW + CD_MW ? need_m : -(1 << 30);
+    int spins = 0;
+    while (true) {
+        // (an atomic load keeps the LDS address space; a volatile access through the reference turns into FLAT)
+        const int v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__all(v >= need)) break;
+        if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+        if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__global__ void __launch_bounds__(256)
-chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-                 int slot_k, double* __restrict__ Linv, int32_t* __restrict__ status, int pending)
+__device__ __forceinline__ void cd_post(CdShared& sh, int flag, int value)
 {
-    if (step >= sel[slot_nblk]) return;
-    // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
-    // chain stops after the last real row, L and L^-1 are the identity there
-    const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
-    const int n_piv4 = (r_here + 3) >> 2;
-    __shared__ double Lf[64 * CD_LD];       // L, column-major
-    __shared__ double Mf[64 * CD_LD];       // L^-1, column-major
-    __shared__ double Tcol[4 * 64];         // [k][row]: pivot columns of the trailing matrix
-    __shared__ double Mrow[4 * 64];         // [k][col]: pivot rows of the running inverse
-    __shared__ double Xs[4 * 64];           // [k][row]: panel, zero at and above the pivot rows
-    __shared__ double Ms[4 * 64];           // [k][col]: L4^-1 M(p,:), zero right of the pivot columns
-    const int t = threadIdx.x, l = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lr = l >> 4, lc = l & 15;
-    double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
-    double* Lout = Linv + (long)step * 64 * 64;
-    // lower-triangle 16 x 16 tiles in row-major order; wave w owns tiles w, w+4, w+8
-    constexpr int TR[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
-    constexpr int TC[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
-    d4 accT[3], accM[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const int idx = wave + 4 * o;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            double vT = 0.0, vM = 0.0;
-            if (idx < 10) {
-                const int row = 16 * TR[idx] + lr + 4 * reg, col = 16 * TC[idx] + lc;
-                // the lower triangle of the global tile is authoritative; mirror it
-                vT = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
-                vM = (row == col) ? 1.0 : 0.0;
-            }
-            accT[o][reg] = vT; accM[o][reg] = vM;
-        }
-    }
-    if (pending) {
-        // Lookahead: the trailing update of step-1 for THIS tile, A(k,k) -= X X^T with X = A(k,k-1)
-        // (already solved by panel(step-1)), is applied here so that the trailing-update kernel of
-        // the previous step can run on a second stream while this block is being factored.
-        const double* Xg = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
-        const int row = t & 63, g = t >> 6;
-        for (int qq = 0; qq < 16; ++qq) { const int c = g + 4 * qq; Lf[c * CD_LD + row] = Xg[row + (long)c * ldA]; }
-        __syncthreads();
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int idx = wave + 4 * o;
-            if (idx < 10) {
-                const int tr = TR[idx], tc = TC[idx];
-#pragma unroll 4
-                for (int kk = 0; kk < 64; kk += 4)
-                    accT[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lf[(kk + lr) * CD_LD + 16 * tr + lc],
-                                                                   -Lf[(kk + lr) * CD_LD + 16 * tc + lc], accT[o], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    {   // pivot block 0: columns 0..3 of the (updated) block, rows 0..3 of the identity
-        const int row = t & 63, k = t >> 6;
-        Mrow[k * 64 + row] = (row == k) ? 1.0 : 0.0;
-        for (int c = k; c < 64; c += 4) { Lf[c * CD_LD + row] = 0.0; Mf[c * CD_LD + row] = 0.0; }
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int idx = wave + 4 * o;
-            if (idx < 10 && TC[idx] == 0 && lc < 4) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Tcol[lc * 64 + 16 * TR[idx] + lr + 4 * reg] = accT[o][reg];
-            }
-        }
-    }
-    __syncthreads();
-    bool bad = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&sh.flags[flag], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to ~2^-48: v_rsq_f64 (2^-24) and ONE Newton step.  The second step of rsqrt_f64 would
+// cost three more instructions per pivot on the chain; the factor is accurate to ~4e-15 instead
+// of 1e-16, far inside the parity tolerance of the state and covariance.
+__device__ __forceinline__ double rsqrt_chain(double d)
+{
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);                // 1 - d y^2
+    return fma(0.5 * y, e, y);                           // y (1 + e/2)
+}
+
+// lower-triangle 16 x 16 tiles in row-major order
+__device__ constexpr int cd_tr(int idx) { return idx < 1 ? 0 : idx < 3 ? 1 : idx < 6 ? 2 : 3; }
+__device__ constexpr int cd_tc(int idx) { return idx - (idx < 1 ? 0 : idx < 3 ? 1 : idx < 6 ? 3 : 6); }
+
+// Panel wave: the pivot chain.
+__device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
+{
+    const int l = threadIdx.x & 63;
+    __builtin_amdgcn_s_setprio(3);                          // the chain wins every issue arbitration on its SIMD
+    double xp0 = 0.0, xp1 = 0.0, xp2 = 0.0, xp3 = 0.0;     // own row of the previous panel
 #pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;
             const int p0 = 16 * sb + 4 * q;
-            if (4 * sb + q >= n_piv4) break;             // uniform: only identity padding is left
-            // ---- A: 4 x 4 Cholesky of the pivot block (uniform, every lane)
+            if (s >= n_piv4) return;                      // uniform: only identity padding is left
             CD_STAMP(s0);
-            const Chol4 c4 = chol4(Tcol, p0);
-            bad = bad || c4.bad;
-            asm volatile("" :: "v"(c4.r3));
+            // strip of block s (T waves, iteration s-1); panel buffer s & 3 free: inverse wave past block
+            // s-3, M waves past iteration s-2; Rs buffer free: inverse wave past block s-2
+            cd_wait<0>(sh, 0, s - 1, s, s - 1);
             CD_STAMP(s1);
-            // ---- B: panel row / inverse column by forward substitution
-            if (t < 128) {
-                const int e = t & 63;
-                const double* src = (t < 64) ? Tcol : Mrow;
-                const double a0 = src[e], a1 = src[64 + e], a2 = src[128 + e], a3 = src[192 + e];
-                const double x0 = a0 * c4.r0;
-                const double x1 = fma(-c4.l10, x0, a1) * c4.r1;
-                const double x2 = fma(-c4.l21, x1, fma(-c4.l20, x0, a2)) * c4.r2;
-                const double x3 = fma(-c4.l32, x2, fma(-c4.l31, x1, fma(-c4.l30, x0, a3))) * c4.r3;
-                if (t < 64) {
-                    // rows of the pivot block hold L4 itself (x_k is then l_{row,k}); entries written
-                    // above the diagonal of L / right of the diagonal of L^-1 are never read
-                    const bool below = e > p0 + 3;
-                    Xs[e] = below ? x0 : 0.0; Xs[64 + e] = below ? x1 : 0.0;
-                    Xs[128 + e] = below ? x2 : 0.0; Xs[192 + e] = below ? x3 : 0.0;
-                    Lf[(p0 + 0) * CD_LD + e] = x0; Lf[(p0 + 1) * CD_LD + e] = x1;
-                    Lf[(p0 + 2) * CD_LD + e] = x2; Lf[(p0 + 3) * CD_LD + e] = x3;
-                } else {
-                    // column e of rows p0..p0+3 of L^-1 (final); nothing right of the pivot columns
-                    const bool left = e <= p0 + 3;
-                    Ms[e] = left ? x0 : 0.0; Ms[64 + e] = left ? x1 : 0.0;
-                    Ms[128 + e] = left ? x2 : 0.0; Ms[192 + e] = left ? x3 : 0.0;
-                    Mf[e * CD_LD + p0 + 0] = x0; Mf[e * CD_LD + p0 + 1] = x1;
-                    Mf[e * CD_LD + p0 + 2] = x2; Mf[e * CD_LD + p0 + 3] = x3;
-                }
-            }
+            const double* Tc = sh.Tst[q & 1];
+            const double* Xp = sh.Xs[(q + 3) & 3];        // panel s-1 (zeros for s = 0)
+            double a0 = Tc[l], a1 = Tc[64 + l], a2 = Tc[128 + l], a3 = Tc[192 + l];
+            // strip row l: T(l, p0+k) -= sum_j X_prev(l, j) X_prev(p0+k, j)
+            a0 = fma(-xp0, Xp[p0 + 0], a0); a1 = fma(-xp0, Xp[p0 + 1], a1); a2 = fma(-xp0, Xp[p0 + 2], a2); a3 = fma(-xp0, Xp[p0 + 3], a3);
+            a0 = fma(-xp1, Xp[64 + p0 + 0], a0); a1 = fma(-xp1, Xp[64 + p0 + 1], a1); a2 = fma(-xp1, Xp[64 + p0 + 2], a2); a3 = fma(-xp1, Xp[64 + p0 + 3], a3);
+            a0 = fma(-xp2, Xp[128 + p0 + 0], a0); a1 = fma(-xp2, Xp[128 + p0 + 1], a1); a2 = fma(-xp2, Xp[128 + p0 + 2], a2); a3 = fma(-xp2, Xp[128 + p0 + 3], a3);
+            a0 = fma(-xp3, Xp[192 + p0 + 0], a0); a1 = fma(-xp3, Xp[192 + p0 + 1], a1); a2 = fma(-xp3, Xp[192 + p0 + 2], a2); a3 = fma(-xp3, Xp[192 + p0 + 3], a3);
+            CD_PIN4(a0, a1, a2, a3);
+            CD_STAMP(sa);
+            // right-looking Cholesky over the 4 columns, lane = row
+            const double r0 = rsqrt_chain(readlane_f64(a0, p0));
+            xp0 = a0 * r0;
+            a1 = fma(-xp0, readlane_f64(xp0, p0 + 1), a1);
+            const double r1 = rsqrt_chain(readlane_f64(a1, p0 + 1));
+            xp1 = a1 * r1;
+            a2 = fma(-xp1, readlane_f64(xp1, p0 + 2), fma(-xp0, readlane_f64(xp0, p0 + 2), a2));
+            const double r2 = rsqrt_chain(readlane_f64(a2, p0 + 2));
+            xp2 = a2 * r2;
+            a3 = fma(-xp2, readlane_f64(xp2, p0 + 3), fma(-xp1, readlane_f64(xp1, p0 + 3), fma(-xp0, readlane_f64(xp0, p0 + 3), a3)));
+            const double r3 = rsqrt_chain(readlane_f64(a3, p0 + 3));
+            xp3 = a3 * r3;
+            CD_PIN4(xp0, xp1, xp2, xp3);
+            CD_STAMP(sc);
+            // rows of the pivot block hold L4 itself (x_k is then l_{row,k}); what lands above the
+            // diagonal of L is never read
+            double* Xc = sh.Xs[q];
+            Xc[l] = xp0; Xc[64 + l] = xp1; Xc[128 + l] = xp2; Xc[192 + l] = xp3;
+            sh.Lf[(p0 + 0) * CD_LD + l] = xp0; sh.Lf[(p0 + 1) * CD_LD + l] = xp1;
+            sh.Lf[(p0 + 2) * CD_LD + l] = xp2; sh.Lf[(p0 + 3) * CD_LD + l] = xp3;
+            if (l == 0) { double* R = sh.Rs[q & 1]; R[0] = r0; R[1] = r1; R[2] = r2; R[3] = r3; }
+            CD_STAMP(sd);
+            cd_post(sh, 0, s + 1);
             CD_STAMP(s2);
-            __syncthreads();
-            CD_STAMP(s3);
-            // ---- C: rank-4 updates of the owned tiles, one MFMA each
-            // (issuing the tiles that feed the next pivot block first was tried: slower code)
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const int idx = wave + 4 * o;
-                if (idx < 10) {
-                    const int tr = TR[idx], tc = TC[idx];
-                    if (16 * tr + 15 > p0 + 3) {                       // some rows of the tile are below the pivot
-                        const double a = Xs[lr * 64 + 16 * tr + lc];
-                        if (16 * tc + 15 > p0 + 3)                     // trailing matrix: T -= X X^T
-                            accT[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Xs[lr * 64 + 16 * tc + lc], accT[o], 0, 0, 0);
-                        if (16 * tc <= p0 + 3)                         // inverse: M -= X (L4^-1 M(p,:))
-                            accM[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Ms[lr * 64 + 16 * tc + lc], accM[o], 0, 0, 0);
-                    }
-                }
-            }
-            CD_STAMP(s4);
-            // ---- D: publish the next pivot block (columns p1..p1+3 of T, rows p1..p1+3 of M)
-            if (p0 + 4 < 64) {
-                const int p1 = p0 + 4, b1 = p1 >> 4, o1 = p1 & 15, q1 = (q + 1) & 3;
-#pragma unroll
-                for (int o = 0; o < 3; ++o) {
-                    const int idx = wave + 4 * o;
-                    if (idx < 10) {
-                        const int tr = TR[idx], tc = TC[idx];
-                        if (tc == b1 && lc >= o1 && lc < o1 + 4) {
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) Tcol[(lc - o1) * 64 + 16 * tr + lr + 4 * reg] = accT[o][reg];
-                        }
-                        if (tr == b1) Mrow[lr * 64 + 16 * tc + lc] = accM[o][q1];   // rows o1 + lr of the tile = register q1
-                    }
-                }
-                if (q1 == 0 && wave == 0) {   // a new block row starts: columns right of its diagonal tile are still identity/zero
-                    for (int cc = 16 * (b1 + 1) + l; cc < 64; cc += 64) {
-                        Mrow[0 * 64 + cc] = 0.0; Mrow[1 * 64 + cc] = 0.0; Mrow[2 * 64 + cc] = 0.0; Mrow[3 * 64 + cc] = 0.0;
-                    }
-                }
-            }
-            CD_STAMP(s5);
-            __syncthreads();
-            CD_STAMP(s6);
-            CD_ACC(0, s0, s1); CD_ACC(1, s1, s2); CD_ACC(2, s2, s3); CD_ACC(3, s3, s4); CD_ACC(4, s4, s5); CD_ACC(5, s5, s6);
-            CD_ACC(6, s0, s6);
+            CD_ACC_T(0, s0, s1, 0); CD_ACC_T(1, s1, sa, 0); CD_ACC_T(5, sa, sc, 0); CD_ACC_T(7, sc, sd, 0); CD_ACC_T(2, sd, s2, 0);
+            CD_ACC_T(6, s0, s2, 0);
         }
     }
+}
+
+// Inverse wave: pivot rows of the running inverse, one block behind the panel wave.
+__device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
+{
+    const int l = threadIdx.x & 63;
+    double mp0 = 0.0, mp1 = 0.0, mp2 = 0.0, mp3 = 0.0;     // own column of Ms of the previous block
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;                     // block
+            const int p0 = 16 * sb + 4 * q;
+            if (s >= n_piv4) return;
+            cd_wait<1>(sh, s + 1, 0, 0, s + 1);           // panel s (L4, reciprocals); strip of block s (M waves, iteration s)
+            const double* Mc = sh.Mst[q & 1];
+            const double* Xp = sh.Xs[(q + 3) & 3];        // panel s-1
+            const double* Xc = sh.Xs[q];                  // panel s: rows p0..p0+3 are L4
+            const double* R = sh.Rs[q & 1];
+            double a0 = Mc[l], a1 = Mc[64 + l], a2 = Mc[128 + l], a3 = Mc[192 + l];
+            {   // strip column l: M(p0+k, l) -= sum_j X_prev(p0+k, j) Ms_prev(j, l)
+                const double ms[4] = {mp0, mp1, mp2, mp3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0 = fma(-Xp[j * 64 + p0 + 0], ms[j], a0); a1 = fma(-Xp[j * 64 + p0 + 1], ms[j], a1);
+                    a2 = fma(-Xp[j * 64 + p0 + 2], ms[j], a2); a3 = fma(-Xp[j * 64 + p0 + 3], ms[j], a3);
+                }
+            }
+            const double l10 = Xc[p0 + 1], l20 = Xc[p0 + 2], l30 = Xc[p0 + 3];
+            const double l21 = Xc[64 + p0 + 2], l31 = Xc[64 + p0 + 3], l32 = Xc[128 + p0 + 3];
+            // entries right of the pivot columns come out as exact zeros (M is lower triangular)
+            mp0 = a0 * R[0];
+            mp1 = fma(-l10, mp0, a1) * R[1];
+            mp2 = fma(-l21, mp1, fma(-l20, mp0, a2)) * R[2];
+            mp3 = fma(-l32, mp2, fma(-l31, mp1, fma(-l30, mp0, a3))) * R[3];
+            double* Mo = sh.Ms[q & 1];
+            Mo[l] = mp0; Mo[64 + l] = mp1; Mo[128 + l] = mp2; Mo[192 + l] = mp3;
+            // column l of rows p0..p0+3 of L^-1 (final)
+            sh.Mf[l * CD_LD + p0 + 0] = mp0; sh.Mf[l * CD_LD + p0 + 1] = mp1;
+            sh.Mf[l * CD_LD + p0 + 2] = mp2; sh.Mf[l * CD_LD + p0 + 3] = mp3;
+            cd_post(sh, 1, s + 1);
+        }
+    }
+}
+
+// T wave B: tiles B and B + 5 of the trailing matrix.
+template <int B>
+__device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const double* tile, long ldA, int pending)
+{
+    const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
+    constexpr int I[2] = {B, B + CD_TW};
+    constexpr int TR0 = cd_tr(I[0]), TC0 = cd_tc(I[0]), TR1 = cd_tr(I[1]), TC1 = cd_tc(I[1]);
+    d4 acc[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * cd_tr(I[o]) + lr + 4 * reg, col = 16 * cd_tc(I[o]) + lc;
+            // the lower triangle of the global tile is authoritative; mirror it
+            acc[o][reg] = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
+        }
+    if (pending) {
+        __syncthreads();                 // (A) the previous panel row is staged in Lf
+        const double* Xg = sh.Lf;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int tr = cd_tr(I[o]), tc = cd_tc(I[o]);
+#pragma unroll 4
+            for (int kk = 0; kk < 64; kk += 4)
+                acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xg[(kk + lr) * CD_LD + 16 * tr + lc],
+                                                              -Xg[(kk + lr) * CD_LD + 16 * tc + lc], acc[o], 0, 0, 0);
+        }
+        __syncthreads();                 // (B) Lf may be cleared
+    }
+    // strip of pivot block 0
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        if (cd_tc(I[o]) == 0 && lc < 4) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) sh.Tst[0][lc * 64 + 16 * cd_tr(I[o]) + lr + 4 * reg] = acc[o][reg];
+        }
+    }
+    __syncthreads();                     // (C) strips, cleared collectors and flags are visible
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;
+            const int p0 = 16 * sb + 4 * q;
+            if (s >= n_piv4) return;
+            CD_STAMP(s0);
+            if (s > 0) {
+                cd_wait<1>(sh, s, 0, 0, 0);                  // panel s-1 (which also means the panel wave is done with strip buffer (s+1) & 1)
+                CD_STAMP(s1);
+                const double* Xp = sh.Xs[(q + 3) & 3];
+                const double a0 = Xp[lr * 64 + 16 * TR0 + lc], b0 = Xp[lr * 64 + 16 * TC0 + lc];
+                const double a1 = Xp[lr * 64 + 16 * TR1 + lc], b1 = Xp[lr * 64 + 16 * TC1 + lc];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, -b0, acc[0], 0, 0, 0);   // T -= X X^T
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, -b1, acc[1], 0, 0, 0);
+                CD_ACC_T(3, s0, s1, 128);
+            }
+            // strip of block s+1 (updates <= s-1 applied)
+            if (p0 + 4 < 64) {
+                const int p1 = p0 + 4, bb = p1 >> 4, o1 = p1 & 15;
+                double* To = sh.Tst[(q + 1) & 1];
+                if (TC0 == bb && lc >= o1 && lc < o1 + 4) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) To[(lc - o1) * 64 + 16 * TR0 + lr + 4 * reg] = acc[0][reg];
+                }
+                if (TC1 == bb && lc >= o1 && lc < o1 + 4) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) To[(lc - o1) * 64 + 16 * TR1 + lr + 4 * reg] = acc[1][reg];
+                }
+            }
+            cd_post(sh, 2 + B, s + 1);
+            CD_STAMP(s2);
+            CD_ACC_T(4, s0, s2, 128);
+        }
+    }
+}
+
+// M wave C: tiles C, C + 3, C + 6 (and 9 for C = 0) of the running inverse.
+template <int C>
+__device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
+{
+    const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
+    constexpr int NT = (C == 0) ? 4 : 3;
+    d4 acc[NT];
+#pragma unroll
+    for (int o = 0; o < NT; ++o)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int idx = C + CD_MW * o;
+            acc[o][reg] = (16 * cd_tr(idx) + lr + 4 * reg == 16 * cd_tc(idx) + lc) ? 1.0 : 0.0;
+        }
+    if (pending) { __syncthreads(); __syncthreads(); }   // (A), (B)
+    __syncthreads();                                      // (C)
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;
+            const int p0 = 16 * sb + 4 * q;
+            if (s >= n_piv4) return;
+            cd_wait<1>(sh, 0, s - 1, 0, 0);                  // Ms of block s-2; the inverse wave is done with strip buffer s & 1
+            if (s > 1) {
+                const double* Xq = sh.Xs[(q + 2) & 3];       // panel s-2
+                const double* Mq = sh.Ms[q & 1];             // Ms of block s-2
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    const int idx = C + CD_MW * o;
+                    acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xq[lr * 64 + 16 * cd_tr(idx) + lc], -Mq[lr * 64 + 16 * cd_tc(idx) + lc],
+                                                                  acc[o], 0, 0, 0);          // M -= X (L4^-1 M(p,:))
+                }
+            }
+            // strip of block s (updates <= s-2 applied): rows p0 + lr of a tile in block row b0 = register q
+            const int b0 = p0 >> 4;
+            double* Mo = sh.Mst[q & 1];
+#pragma unroll
+            for (int o = 0; o < NT; ++o) {
+                const int idx = C + CD_MW * o;
+                if (cd_tr(idx) == b0) Mo[lr * 64 + 16 * cd_tc(idx) + lc] = acc[o][q];
+            }
+            cd_post(sh, 2 + CD_TW + C, s + 1);
+        }
+    }
+}
+
+__device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
+                                                const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
+                                                int32_t* __restrict__ status, int pending)
+{
+    // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
+    // chain stops after the last real row, L and L^-1 are the identity there
+    const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
+    const int n_piv4 = (r_here + 3) >> 2;
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
+    double* Lout = Linv + (long)step * 64 * 64;
+    {
+        const int row = t & 63, g = t >> 6;
+        if (pending) {
+            // Lookahead: the trailing update of step-1 for THIS tile, A(k,k) -= X X^T with X = A(k,k-1)
+            // (already solved by panel(step-1)), is applied by the T waves so that the trailing-update
+            // kernel of the previous step can run elsewhere while this block is factored.
+            const double* Xg = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
+            for (int c = g; c < 64; c += CD_THREADS / 64) sh.Lf[c * CD_LD + row] = Xg[row + (long)c * ldA];
+        }
+        if (t < 16) sh.flags[t] = 0;
+        if (t == 16) sh.timeout = 0;
+        if (g < 4) sh.Xs[3][g * 64 + row] = 0.0;                                         // "panel" -1
+        else if (g < 8) { sh.Mst[0][(g - 4) * 64 + row] = 0.0; sh.Mst[1][(g - 4) * 64 + row] = 0.0; }
+    }
+    if (wave == 0 || wave == 1) {
+        if (pending) { __syncthreads(); __syncthreads(); }          // (A), (B)
+        {   // L, L^-1 collectors cleared
+            const int row = t & 63, g = t >> 6;      // g = 0, 1
+            for (int c = g; c < 64; c += 2) { sh.Lf[c * CD_LD + row] = 0.0; sh.Mf[c * CD_LD + row] = 0.0; }
+        }
+        __syncthreads();                                             // (C)
+        if (wave == 0) cd_panel_wave(sh, n_piv4);
+        else cd_inverse_wave(sh, n_piv4);
+    } else {
+        switch (wave) {
+        case 2: cd_t_wave<0>(sh, n_piv4, tile, ldA, pending); break;
+        case 3: cd_t_wave<1>(sh, n_piv4, tile, ldA, pending); break;
+        case 4: cd_t_wave<2>(sh, n_piv4, tile, ldA, pending); break;
+        case 5: cd_t_wave<3>(sh, n_piv4, tile, ldA, pending); break;
+        case 6: cd_t_wave<4>(sh, n_piv4, tile, ldA, pending); break;
+        case 7: cd_m_wave<0>(sh, n_piv4, pending); break;
+        case 8: cd_m_wave<1>(sh, n_piv4, pending); break;
+        default: cd_m_wave<2>(sh, n_piv4, pending); break;
+        }
+    }
+    __syncthreads();
+    bool bad = false;
     {
         const int i = t & 63, g = t >> 6;
         const int done = 4 * n_piv4;                 // pivots processed; beyond them L = L^-1 = I
-        for (int qq = 0; qq < 16; ++qq) {
-            const int c = g + 4 * qq;
+        for (int c = g; c < 64; c += CD_THREADS / 64) {
             const bool pad = (c >= done);
-            const double lv = pad ? ((i == c) ? 1.0 : 0.0) : Lf[c * CD_LD + i];
-            const double mv = (i >= done) ? ((i == c) ? 1.0 : 0.0) : Mf[c * CD_LD + i];
+            const double lv = pad ? ((i == c) ? 1.0 : 0.0) : sh.Lf[c * CD_LD + i];
+            const double mv = (i >= done) ? ((i == c) ? 1.0 : 0.0) : sh.Mf[c * CD_LD + i];
+            if (i == c && !(lv > 0.0 && lv < 1.0e300)) bad = true;      // a non-positive pivot turns the diagonal into NaN / 0 / inf
             Lout[i + 64 * c] = (i >= c) ? mv : 0.0;
             if (i >= c) tile[i + (long)c * ldA] = lv;
         }
     }
-    if (bad && l == 0) atomicMin(status, -6);        // RSLAM_ERR_NOT_SPD
+    if (bad) atomicMin(status, -6);                              // RSLAM_ERR_NOT_SPD
+    if (t == 0 && sh.timeout) atomicMin(status, -3);             // RSLAM_ERR_HIP: hand-over protocol broke (never expected)
+}
+
+__global__ void __launch_bounds__(CD_THREADS)
+chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+                 int slot_k, double* __restrict__ Linv, int32_t* __restrict__ status, int pending)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (step >= sel[slot_nblk]) return;
+    cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step, sel, slot_k, Linv, status, pending);
 }
 
 // rows of block b participate in step `step` of a sweep with nblk column blocks?
@@ -805,15 +978,11 @@ panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     store_tile(lds, tile, ldA);
 }
 
-__global__ void __launch_bounds__(256)
-trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-             int rp_blocks, int skip_next_diag)
+__device__ __forceinline__ void trail_tile(double* __restrict__ A, long ldA, int step, int nblk, int rp_blocks,
+                                           int i, int j, int skip_next_diag, double* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int nblk = sel[slot_nblk];
-    const int i = blockIdx.x, j = blockIdx.y + step + 1;
     if (step >= nblk || j >= nblk || i < j) return;
-    if (skip_next_diag && i == step + 1 && j == step + 1) return;   // applied by chol_diag_kernel(step+1) itself
+    if (skip_next_diag && i == step + 1 && j == step + 1) return;   // applied by the diagonal-block factorisation itself
     if (!row_block_active(i, step, nblk, rp_blocks)) return;
     const double* Ai = A + (long)i * 64 + (long)step * 64 * ldA;
     const double* Aj = A + (long)j * 64 + (long)step * 64 * ldA;
@@ -834,6 +1003,38 @@ trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     }
 }
 
+__global__ void __launch_bounds__(256)
+trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+             int rp_blocks, int skip_next_diag)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    trail_tile(A, ldA, step, sel[slot_nblk], rp_blocks, blockIdx.x, blockIdx.y + step + 1, skip_next_diag, lds);
+}
+
+// Trailing update of step k and the factorisation of diagonal block k+1 in ONE launch: workgroup 0
+// applies the step-k update to tile (k+1,k+1) itself (cd_factor_block, pending) and factors it while
+// the other workgroups update the remaining tiles, so the serial chain per block step is
+// panel + max(trailing, diagonal) instead of their sum.  All workgroups have the diagonal block's
+// shape (CD_THREADS); the tile workgroups retire their surplus waves at once.
+__global__ void __launch_bounds__(CD_THREADS)
+trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+                  int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int nblk = sel[slot_nblk];
+    if (step + 1 >= nblk) return;                                 // no trailing matrix left
+    if (blockIdx.x == 0) {
+        cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 1);
+        return;
+    }
+    if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
+    const int b = blockIdx.x - 1;
+    trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
+}
+
+// dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
+constexpr size_t CD_LDS_BYTES = sizeof(CdShared) > sizeof(double) * TG_LDS_DOUBLES ? sizeof(CdShared) : sizeof(double) * TG_LDS_DOUBLES;
+
 #if defined(CD_STAMPS)
 int debug_read_cd_stamps(unsigned long long* out, int reset)
 {
@@ -851,14 +1052,18 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }
 
-// Single stream: diag(k) panel(k) trail(k) per block step.
-// A two-stream lookahead variant (aux != nullptr: diag(k+1) applies the step-k update of its own
-// tile and trail(k) runs on a second stream, fork/join by events) is kept for measurement only:
-// on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the 7 us trailing
-// kernels they hide (C3 frame 0.68 ms against 0.52 ms single-stream, eager and hipGraph alike).
+// One stream: diag(0), then per block step panel(k) and the fused trail(k) + diag(k+1).
+// RSLAM_SWEEP_UNFUSED=1 selects the three-kernels-per-step sequence (diag(k) panel(k) trail(k)) for
+// measurement.  A two-stream lookahead variant (aux != nullptr) is kept for measurement only:
+// on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the trailing kernels
+// they hide (C3 frame 0.68 ms against 0.52 ms single-stream, eager and hipGraph alike).
 void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
                          const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Linv,
                          int32_t* status_sel)
@@ -868,8 +1073,20 @@ void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * r
     const int row_blocks = d.ldA / 64;
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
     const bool two = (aux != nullptr && ev != nullptr);
+    static const bool unfused = getenv("RSLAM_SWEEP_UNFUSED") != nullptr;
+    if (!two && !unfused) {
+        if (steps <= 0) return;
+        chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
+        for (int step = 0; step < steps; ++step) {
+            panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
+            if (step + 1 < steps)
+                trail_diag_kernel<<<dim3(1 + row_blocks * (steps - step - 1)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
+                    A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+        }
+        return;
+    }
     for (int step = 0; step < steps; ++step) {
-        chol_diag_kernel<<<dim3(1), dim3(256), 0, s>>>(A, d.ldA, step, sel, slot_nblk, slot_k, Linv, status_sel, (two && step > 0) ? 1 : 0);
+        chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, step, sel, slot_nblk, slot_k, Linv, status_sel, (two && step > 0) ? 1 : 0);
         if (two && step > 0) (void)hipStreamWaitEvent(s, ev[2 * (step - 1) + 1], 0);      // trail(step-1) done
         panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
         if (step + 1 < steps) {

@@ -20,6 +20,6 @@ for _ in range(N):
 L.rslam_debug_cd_stamps(ctx._h, out, 1)
 v = np.array(list(out), dtype=float)
 steps = N * (1 + 7 * 16 + 13)      # LI: 1 pivot step; HI: 7 full blocks + 13 steps
-names = ["A chol4", "B subst", "wait->barrier1", "C mfma", "D publish", "barrier2", "total"]
-for n, x in zip(names, v[:7]):
+names = ["chain wait", "chain lds read+strip", "chain post", "T wave wait", "T wave total", "chain chol", "chain total", "chain lds write"]
+for n, x in zip(names, v[:8]):
     print(f"{n:16s} {x / steps:9.1f} cycles per 4-pivot step  ({100 * x / max(v[6], 1):5.1f} %)")
