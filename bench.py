@@ -246,6 +246,8 @@ def main():
         out["dropin_ms_per_frame"] = {"value": float(np.median(t_drop[1:]) * 1e3),
                                       "note": "rslam_predict + rslam_ransac_update with pageable host buffers: "
                                               "26.3 MB of P up and down per frame; never the headline value"}
+        # widened rows of SURVEY 8(f), timed beside their oracle restatements (host calls incl. transfers + sync)
+        out["widened_rows"] = widened_rows(ctx, frame)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(frame, default_config(compat=args.compat, adaptive=0), args.cpu_sample_iters)
     if rank == 0:
@@ -254,6 +256,42 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def widened_rows(ctx, frame):
+    """ms per call of the SURVEY 8(f) rows on the device next to the oracle's CPU restatement (1 thread):
+    ekf_prediction, NCC search, map surgery (delete + insert).  Not part of the headline value."""
+    from oracle import pyoracle          # checker / CPU baseline only
+    from ransac_slam_amd import default_camera
+    from ransac_slam_amd.synth import make_match_inputs
+    cam = default_camera()
+    res = {}
+
+    def med(fn, n=5):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[1:]) * 1e3)
+
+    h, vis, S = ctx.predict(frame.types, frame.x_pred, frame.P_pred)
+    image, patches, _ = make_match_inputs(cam, np.nan_to_num(h), vis, seed=5)
+    res["ncc_search"] = {"gpu_ms": med(lambda: ctx.match(image, patches)),
+                         "cpu_oracle_ms": med(lambda: pyoracle.matching(cam, image, patches, np.nan_to_num(h), vis, np.nan_to_num(S)), 3),
+                         "note": "rslam_match: image + patches H2D, search, z/ic D2H; %d features" % frame.L}
+    ctx.ransac_update(frame.z, (frame.ic & vis).astype(np.uint8), frame.draws, want_P=False)
+    res["ekf_prediction"] = {"gpu_ms": med(lambda: (ctx.ekf_prediction(1.0, 0.007, 0.007), ctx.sync_stream())),
+                             "cpu_oracle_ms": med(lambda: pyoracle.ekf_prediction(frame.x_pred, frame.P_pred, 1.0, 0.007, 0.007), 3)}
+    x, P = frame.x_pred, np.asarray(frame.P_pred)
+
+    def gpu_edit():
+        ctx.map_add_feature([150.0, 110.0]); ctx.map_delete_feature(ctx.L - 1)
+    ctx.set_posterior(frame.types, x, P)
+    res["map_insert_delete"] = {"gpu_ms": med(gpu_edit),
+                                "cpu_oracle_ms": med(lambda: pyoracle.map_delete_feature(
+                                    np.append(frame.types, 0).astype(np.uint8),
+                                    *pyoracle.map_add_feature(cam, 1.0, x, P, np.array([150.0, 110.0])), frame.L), 3),
+                                "note": "one insertion (n+6) and one deletion on the resident posterior, each with its sync"}
+    return res
 
 
 if __name__ == "__main__":

@@ -137,6 +137,18 @@ int rslam_set_posterior (rslam_ctx* ctx, const rslam_layout* layout, const doubl
 int rslam_ekf_prediction(rslam_ctx* ctx, double delta_t, double std_a, double std_alpha);
 int rslam_fetch_prior   (rslam_ctx* ctx, double* x_pred /* host n, may be NULL */, double* P_pred /* host n*n, may be NULL */);
 
+/* Tracking::matching (Tracking.cpp:279-351): the NCC search between the two segments,
+ * on the h / S that rslam_predict left on the device.  image: cam.nRows * cam.nCols uint8, row-major (the
+ * cv::Mat of the frame); patches: L * 169 doubles, feature f's predicted 13 x 13 patch
+ * (features_info[f].patch_when_matching, column-major, written by pred_patch_fc at Tracking.cpp:277;
+ * ignored where the feature was not predicted).  Outputs (host): z (L*2) = (column, row) of the best
+ * candidate where ic[f] = 1; ic (L) = individually_compatible; corr (L, may be NULL) = best normalised
+ * correlation (-2 when the feature was not searched or had no candidate).  The correlation is
+ * Converter::corrcoef_opencv's (Converter.cpp:188-209: patches through float32, accumulation in double),
+ * threshold 0.80 and gate 5.9915 as at Tracking.cpp:281-283; candidates are visited column by column and
+ * the first maximum wins, as Eigen's maxCoeff does (:342). */
+int rslam_match(rslam_ctx* ctx, const uint8_t* image, const double* patches, double* z, uint8_t* ic, double* corr);
+
 /* Map::map_management's edits of x_k_k / p_k_k on the resident posterior, so
  * that the covariance never leaves HBM between frames.  The host keeps features_info (patches,
  * counters) and mirrors each call there; the context tracks the layout (rslam_get_layout).

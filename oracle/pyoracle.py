@@ -70,6 +70,8 @@ def lib():
         L.orc_map_add_feature.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]
         L.orc_hinv.argtypes = [C.c_void_p, _dp, _dp, C.c_double, _dp]
         L.orc_add_feature_jacobians.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
+        L.orc_matching.argtypes = [C.c_void_p, _u8p, C.c_int, _dp, C.c_int, _dp, _u8p, _dp, _dp, _u8p, _dp, _dp]
+        L.orc_matching.restype = None
         L.orc_ekf_prediction.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         L.orc_motion_model.argtypes = [_dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]
         _lib = L
@@ -337,3 +339,18 @@ def add_feature_jacobians(cam, std_z, std_rho, uvd, Xv):
     D = np.zeros((6, 13), order="F"); Rn = np.zeros((6, 6), order="F")
     lib().orc_add_feature_jacobians(C.byref(cam), std_z, std_rho, _p(uvd), _p(Xv), _p(D), _p(Rn))
     return D, Rn
+
+
+def matching(cam, image, patches, h, has_h, S, half=6):
+    """Tracking::matching.  image (nRows, nCols) uint8; patches (L, 13, 13) with patches[f][r, c] the
+    predicted patch (stored column-major per feature like Eigen); -> z (L,2), ic (L), corr (L), margins (3)"""
+    image = np.ascontiguousarray(image, np.uint8)
+    L = len(has_h)
+    side = 2 * half + 1
+    pt = np.ascontiguousarray(np.transpose(np.asarray(patches, np.float64).reshape(L, side, side), (0, 2, 1)))  # col-major per feature
+    h = np.ascontiguousarray(h, np.float64); S = np.ascontiguousarray(S, np.float64)
+    has_h = np.ascontiguousarray(has_h, np.uint8)
+    z = np.zeros((L, 2)); ic = np.zeros(L, np.uint8); corr = np.zeros(L); m = np.zeros(3)
+    lib().orc_matching(C.byref(cam), _p(image, _u8p), L, _p(pt), half, _p(h), _p(has_h, _u8p), _p(S), _p(z), _p(ic, _u8p),
+                       _p(corr), _p(m))
+    return z, ic, corr, m

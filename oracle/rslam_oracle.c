@@ -1387,6 +1387,106 @@ int orc_map_add_feature(const rslam_camera* cam, double std_z, int n, const doub
 }
 
 /* ------------------------------------------------------------------ */
+/* NCC search: Tracking::matching, Tracking.cpp:279-351  */
+/* with Converter::corrcoef_opencv, Converter.cpp:188-209                  */
+/* ------------------------------------------------------------------ */
+
+/* One feature.  image: nRows x nCols uint8, row-major (cv::Mat);  patch: 13 x 13 predicted patch,
+ * column-major as Eigen stores patch_when_matching;  h, S: prediction and innovation covariance
+ * (col-major 2 x 2).  Returns 1 when a match above the correlation threshold exists and writes
+ * z = (column j, row i).  best_corr receives the maximum correlation over the candidates (or -2
+ * when there is no candidate), n_cand their number.  margins[0..2] (nullable): smallest distance of
+ * the largest eigenvalue of S to 100, of a candidate's Mahalanobis distance to the gate and of the
+ * best correlation to the threshold / to the runner-up -- the decisions that must not be close calls
+ * for integer outputs to be comparable.
+ *
+ * corrcoef_opencv: the patches go through toCvMat_f (float32), cv::calcCovarMatrix(..., CV_COVAR_NORMAL |
+ * CV_COVAR_ROWS) accumulates in double; the common 1/(cols-1) factor cancels in the normalisation
+ * (Converter.cpp:196,204-206).  OpenCV is not in this image: the summation order of its covariance is
+ * unpinned; this restatement uses the two-pass definition in double.  Only row 0 of the matrix is read
+ * (Tracking.cpp:340), so only that row is formed. */
+int orc_match_feature(const rslam_camera* cam, const uint8_t* image, const double* patch, int half,
+                      const double h[2], const double S[4], double corr_threshold, double chi2,
+                      double z[2], double* best_corr, int* n_cand, double margins[3])
+{
+    const int side = 2 * half + 1, npix = side * side;
+    const int nCols = cam->nCols, nRows = cam->nRows;
+    *best_corr = -2.0; *n_cand = 0;
+    if (margins) { margins[0] = margins[1] = margins[2] = 1e300; }
+    /* SelfAdjointEigenSolver reads the lower triangle: closed form for 2 x 2 */
+    const double a = S[0], b = S[1], d = S[3];
+    const double lmax = 0.5 * (a + d) + sqrt(0.25 * (a - d) * (a - d) + b * b);
+    if (margins) margins[0] = fabs(lmax - 100.0);
+    if (!(lmax < 100)) return 0;                                                    /* Tracking.cpp:303 */
+    const int hsx = (int)ceil(2 * sqrt(S[0])), hsy = (int)ceil(2 * sqrt(S[3]));   /* :306-307 */
+    double Sinv[4];
+    orc_inverse_lu(2, S, Sinv);
+    /* predicted patch as float32, its mean and centred energy */
+    double* p = (double*)malloc(sizeof(double) * (size_t)npix);
+    double pm = 0;
+    for (int k = 0; k < npix; ++k) { p[k] = (double)(float)patch[k]; pm += p[k]; }
+    pm /= npix;
+    double pe = 0;
+    for (int k = 0; k < npix; ++k) pe += (p[k] - pm) * (p[k] - pm);
+    const int x0 = (int)round(h[0]), y0 = (int)round(h[1]);
+    double best = -2.0, second = -2.0; int bj = 0, bi = 0, count = 0;
+    for (int j = x0 - hsx; j <= x0 + hsx; ++j)
+        for (int i = y0 - hsy; i <= y0 + hsy; ++i) {
+            const double n0 = j - h[0], n1 = i - h[1];
+            /* (nu' * S^-1) * nu, left to right */
+            const double t0 = n0 * Sinv[0] + n1 * Sinv[1], t1 = n0 * Sinv[2] + n1 * Sinv[3];
+            const double d2 = t0 * n0 + t1 * n1;
+            if (margins && fabs(d2 - chi2) < margins[1]) margins[1] = fabs(d2 - chi2);
+            if (!(d2 < chi2)) continue;
+            if (!((j > half) && (j < nCols - half) && (i > half) && (i < nRows - half))) continue;
+            /* candidate patch: element (r, c) = image(i - half + r, j - half + c), reshaped column-major */
+            double cm = 0;
+            for (int c = 0; c < side; ++c)
+                for (int r = 0; r < side; ++r) cm += image[(size_t)(i - half + r) * nCols + (j - half + c)];
+            cm /= npix;
+            double ce = 0, pc = 0;
+            for (int c = 0; c < side; ++c)
+                for (int r = 0; r < side; ++r) {
+                    const double v = image[(size_t)(i - half + r) * nCols + (j - half + c)] - cm;
+                    ce += v * v;
+                    pc += (p[r + side * c] - pm) * v;
+                }
+            const double corr = pc / sqrt(pe * ce);
+            ++count;
+            if (corr > best) { second = best; best = corr; bj = j; bi = i; }     /* maxCoeff: first maximum */
+            else if (corr > second) second = corr;
+        }
+    free(p);
+    *n_cand = count;
+    if (count == 0) return 0;               /* (the reference takes maxCoeff of an empty vector here) */
+    *best_corr = best;
+    if (margins) {
+        margins[2] = fabs(best - corr_threshold);
+        if (count > 1 && best - second < margins[2] && best > corr_threshold) margins[2] = best - second;
+    }
+    if (best > corr_threshold) { z[0] = bj; z[1] = bi; return 1; }
+    return 0;
+}
+
+/* Tracking::matching over all features; has_h (L) = prediction exists.  Outputs z (L*2, written where
+ * ic), ic (L), corr (L, -2 where no candidate / not searched), margins[3] minima over the features. */
+void orc_matching(const rslam_camera* cam, const uint8_t* image, int L, const double* patches, int half,
+                  const double* h, const uint8_t* has_h, const double* S, double* z, uint8_t* ic, double* corr,
+                  double margins[3])
+{
+    const int npix = (2 * half + 1) * (2 * half + 1);
+    if (margins) margins[0] = margins[1] = margins[2] = 1e300;
+    for (int f = 0; f < L; ++f) {
+        ic[f] = 0; corr[f] = -2.0;
+        if (!has_h[f]) continue;
+        double m[3]; int nc;
+        ic[f] = (uint8_t)orc_match_feature(cam, image, patches + (size_t)f * npix, half, h + 2 * f, S + 4 * f, 0.80, 5.9915,
+                                           z + 2 * f, corr + f, &nc, m);
+        if (margins) for (int k = 0; k < 3; ++k) if (m[k] < margins[k]) margins[k] = m[k];
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* introspection                                                        */
 /* ------------------------------------------------------------------ */
 

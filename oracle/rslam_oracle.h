@@ -103,6 +103,13 @@ void orc_hinv(const rslam_camera* cam, const double uvd[2], const double Xv[13],
               double y[6]);                                                                 /* ExtendKF.cpp:236-265 */
 void orc_add_feature_jacobians(const rslam_camera* cam, double std_z, double std_rho, const double uvd[2],
                                const double Xv[13], double D[78], double Rn[36]);           /* Map.cpp:339-388 */
+/* NCC search: Tracking::matching, Tracking.cpp:279-351 + Converter::corrcoef_opencv */
+int  orc_match_feature(const rslam_camera* cam, const uint8_t* image, const double* patch, int half,
+                       const double h[2], const double S[4], double corr_threshold, double chi2,
+                       double z[2], double* best_corr, int* n_cand, double margins[3]);
+void orc_matching(const rslam_camera* cam, const uint8_t* image, int L, const double* patches, int half,
+                  const double* h, const uint8_t* has_h, const double* S, double* z, uint8_t* ic, double* corr,
+                  double margins[3]);
 /* dynamic-size inverse as Eigen does it (PartialPivLU), Tracking.cpp:421 */
 int  orc_inverse_lu(int n, const double* A, double* Ainv);
 

@@ -31,6 +31,7 @@ SYMBOLS = {
     "rslam_set_posterior": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp]),
     "rslam_ekf_prediction": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "rslam_fetch_prior": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "rslam_match": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _u8p, _dp]),
     "rslam_map_delete_feature": (C.c_int, [C.c_void_p, C.c_int32]),
     "rslam_map_convert": (C.c_int, [C.c_void_p, C.c_double, _i32p, _dp]),
     "rslam_map_add_feature": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
@@ -148,6 +149,15 @@ class RslamHip:
     def ekf_prediction(self, delta_t=1.0, std_a=0.007, std_alpha=0.007):
         _chk(lib().rslam_ekf_prediction(self._h, delta_t, std_a, std_alpha), "rslam_ekf_prediction")
 
+    # ---- Tracking::matching on the resident prediction ---------------------
+    def match(self, image, patches):
+        """image (nRows, nCols) uint8; patches (L, 13, 13) with patches[f][row, col] -> z (L,2), ic (L), corr (L)"""
+        image = np.ascontiguousarray(image, np.uint8)
+        pt = np.ascontiguousarray(np.transpose(np.asarray(patches, np.float64).reshape(self.L, 13, 13), (0, 2, 1)))
+        z = np.zeros((max(self.L, 1), 2)); ic = np.zeros(max(self.L, 1), np.uint8); corr = np.zeros(max(self.L, 1))
+        _chk(lib().rslam_match(self._h, _p(image, _u8p), _p(pt), _p(z), _p(ic, _u8p), _p(corr)), "rslam_match")
+        return z[:self.L], ic[:self.L], corr[:self.L]
+
     # ---- Map::map_management state surgery on the resident posterior -------
     def get_layout(self):
         n, L = C.c_int32(), C.c_int32()
@@ -188,6 +198,10 @@ class RslamHip:
         _chk(lib().rslam_fetch_state(self._h, _p(x)), "rslam_fetch_state")
         _chk(lib().rslam_fetch_cov(self._h, _p(P)), "rslam_fetch_cov")
         return x, P
+
+    def sync_stream(self):
+        """wait for everything enqueued so far (no frame status involved)"""
+        _chk(lib().rslam_fetch_prior(self._h, None, None), "rslam_fetch_prior")
 
     def fetch_prior(self):
         x = np.zeros(self.n)

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librslam_hip.so")
-SOURCES = ["kernels.hip", "map_kernels.hip", "rslam_api.hip"]
+SOURCES = ["kernels.hip", "map_kernels.hip", "match_kernels.hip", "rslam_api.hip"]
 HEADERS = ["kernels.h", "tile_gemm.h", "camera_model.h", os.path.join("..", "..", "include", "rslam.h")]
 
 

@@ -92,6 +92,10 @@ void launch_map_cov(hipStream_t s, const double* P, int ld_old, double* Pn, int 
                     int shift, int sp_base, int sp_cnt, int add_r, const double* coef);
 void launch_map_linearity(hipStream_t s, const double* x, const double* P, int NP, int L, const uint8_t* type,
                           const int32_t* off, double threshold, double* out, int32_t* first);
+// match_kernels.hip: Tracking::matching (NCC search) on the resident prediction
+void launch_match(hipStream_t s, const Cam& cam, const uint8_t* image, const double* patches, int L, const double* h,
+                  const uint8_t* has_h, const double* S, double corr_threshold, double chi2, double* z, uint8_t* ic,
+                  double* corr);
 int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kernels (80 KiB)
 int init_kernel_attributes2();
 void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,

@@ -73,7 +73,8 @@ struct rslam_ctx {
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Linv,
-                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin;
+                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr;
+    DevBuf<uint8_t> d_image;
     DevBuf<int32_t> d_first;
     // timing
     int timing = 0;
@@ -167,6 +168,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release();
+    c->d_patches.release(); c->d_corr.release(); c->d_image.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -583,6 +585,32 @@ extern "C" int rslam_predict(rslam_ctx* c, const rslam_layout* layout, const dou
         if (h) { h[2 * i] = hh[2 * i]; h[2 * i + 1] = hh[2 * i + 1]; }
         if (S) memcpy(S + 4 * i, SS.data() + 4 * i, sizeof(double) * 4);
     }
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// Tracking::matching on the resident prediction
+// ------------------------------------------------------------------------
+extern "C" int rslam_match(rslam_ctx* c, const uint8_t* image, const double* patches, double* z, uint8_t* ic, double* corr)
+{
+    if (!c || !image || !patches || !z || !ic) return RSLAM_ERR_ARG;
+    if (!c->have_state || !c->predicted) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const int L = c->L;
+    if (L == 0) return RSLAM_OK;
+    const size_t npix = (size_t)c->cam.nRows * c->cam.nCols;
+    if (c->d_image.ensure(npix) < 0 || c->d_patches.ensure((size_t)L * 169) < 0 || c->d_corr.ensure(L) < 0) return RSLAM_ERR_HIP;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_image.p, image, npix, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_patches.p, patches, sizeof(double) * (size_t)L * 169, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_z.p, 0, sizeof(double) * 2 * L, s));
+    launch_match(s, c->cam, c->d_image.p, c->d_patches.p, L, c->d_h.p, c->d_hash.p, c->d_S.p, 0.80 /* Tracking.cpp:281 */,
+                 5.9915 /* :283 */, c->d_z.p, c->d_ic.p, c->d_corr.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(z, c->d_z.p, sizeof(double) * 2 * L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ic, c->d_ic.p, L, hipMemcpyDeviceToHost, s));
+    if (corr) HIPCHK(hipMemcpyAsync(corr, c->d_corr.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return RSLAM_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <stdexcept>
 #include <string>
 #include <array>
+#include <cstring>
 #include <vector>
 
 #include "../../include/rslam.h"
@@ -60,6 +61,7 @@ struct Feature {
     VectorXd z;                          // 2 entries when matched, empty otherwise
     VectorXd h;                          // 2 entries when predicted visible, empty otherwise
     MatrixXd S;                          // 2 x 2
+    MatrixXd patch_when_matching;        // 13 x 13, written by pred_patch_fc (Tracking.cpp:277)
 };
 
 // ExtendKF members and methods on the hot path (ExtendKF.h:154-169)
@@ -167,6 +169,29 @@ public:
             f.h.resize(2); f.h(0) = h[2 * i]; f.h(1) = h[2 * i + 1];
             f.S.resize(2, 2);
             for (int q = 0; q < 4; ++q) f.S.v[q] = S[4 * i + q];
+        }
+    }
+
+    // Tracking::matching (Tracking.cpp:279-351): the NCC search on the device, on the h / S that
+    // search_IC_matches_predict left there.  image = the frame's cv::Mat data (uint8, nRows x nCols,
+    // row-major); the predicted patches come from pred_patch_fc, which stays on the host.
+    void matching(const uint8_t* image)
+    {
+        ExtendKF& k = *mT_ExtendKF;
+        const int L = (int)k.features_info.size();
+        std::vector<double> patches((size_t)L * 169 + 1, 0.0), z(2 * (size_t)L + 1);
+        std::vector<uint8_t> ic((size_t)L + 1);
+        for (int i = 0; i < L; ++i) {
+            const MatrixXd& pm = k.features_info[i].patch_when_matching;
+            if (pm.rows() == 13 && pm.cols() == 13) std::memcpy(&patches[(size_t)i * 169], pm.data(), sizeof(double) * 169);
+        }
+        const int rc = rslam_match(k.ctx(), image, patches.data(), z.data(), ic.data(), nullptr);
+        if (rc) throw Error(rc, "rslam_match");
+        for (int i = 0; i < L; ++i) {
+            Feature& f = k.features_info[i];
+            if (!ic[i]) continue;
+            f.individually_compatible = true;                       // Tracking.cpp:345
+            f.z.resize(2); f.z(0) = z[2 * i]; f.z(1) = z[2 * i + 1];   // :346
         }
     }
 

@@ -162,3 +162,35 @@ def make_config_frame(config_id: int) -> Frame:
     """The frames of BASELINE.json configs 1..4 (all inverse-depth landmarks)."""
     c = CONFIGS[config_id]
     return make_frame(L=c["L"], H=c["H"], seed=config_id)
+
+
+def make_match_inputs(cam, h, visible, seed=0, offset_px=2.0, noise=3.0, frac_unmatched=0.15):
+    """Synthetic inputs of the NCC search (Tracking::matching): a random 8-bit image of the camera's
+    size and, per feature, the 13 x 13 patch the reference would have predicted (pred_patch_fc):
+    the image around a point a few pixels from h plus noise, or an unrelated patch for
+    `frac_unmatched` of the features.  Returns image (nRows, nCols) uint8, patches (L, 13, 13)
+    float64 with patches[f][row, col], truth (L, 2) = (column, row) of the planted match or -1."""
+    rng = np.random.default_rng(SEED_BASE + 0x3A7C0000 + seed)
+    nR, nC = int(cam.nRows), int(cam.nCols)
+    # low-pass filtered noise: correlation peaks are unique but neighbours are not independent
+    base = rng.normal(0.0, 1.0, (nR + 8, nC + 8))
+    k = np.array([1.0, 4.0, 6.0, 4.0, 1.0]); k /= k.sum()
+    for ax in (0, 1):
+        base = sum(np.roll(base, s - 2, axis=ax) * k[s] for s in range(5))
+    base = base[4:-4, 4:-4]
+    image = np.clip(128.0 + 60.0 * base / base.std(), 0, 255).astype(np.uint8)
+    L = len(visible)
+    patches = np.zeros((L, 13, 13))
+    truth = -np.ones((L, 2))
+    for f in range(L):
+        if not visible[f]:
+            continue
+        if rng.random() < frac_unmatched:
+            patches[f] = rng.uniform(0, 255, (13, 13))
+            continue
+        x = int(round(h[f, 0] + rng.uniform(-offset_px, offset_px)))
+        y = int(round(h[f, 1] + rng.uniform(-offset_px, offset_px)))
+        x = min(max(x, 7), nC - 8); y = min(max(y, 7), nR - 8)
+        patches[f] = image[y - 6:y + 7, x - 6:x + 7] + rng.normal(0.0, noise, (13, 13))
+        truth[f] = (x, y)
+    return image, patches, truth
