@@ -278,6 +278,14 @@ def widened_rows(ctx, frame):
     res["ncc_search"] = {"gpu_ms": med(lambda: ctx.match(image, patches)),
                          "cpu_oracle_ms": med(lambda: pyoracle.matching(cam, image, patches, np.nan_to_num(h), vis, np.nan_to_num(S)), 3),
                          "note": "rslam_match: image + patches H2D, search, z/ic D2H; %d features" % frame.L}
+    from ransac_slam_amd.synth import make_feature_records
+    uv_f, R_f, r_f, patch_f = make_feature_records(cam, frame, seed=5)
+    ctx.set_feature_records(uv_f, R_f, r_f, patch_f)
+    res["patch_prediction"] = {"gpu_ms": med(lambda: ctx.predict_patches(fetch=False)),
+                               "cpu_oracle_ms": med(lambda: pyoracle.pred_patches(cam, 1, frame.types, frame.offsets, frame.x_pred,
+                                                                                  h, vis, uv_f, R_f, r_f, patch_f), 3),
+                               "note": "rslam_predict_patches on the resident feature store (records uploaded once), "
+                                       "patches left on the device"}
     ctx.ransac_update(frame.z, (frame.ic & vis).astype(np.uint8), frame.draws, want_P=False)
     res["ekf_prediction"] = {"gpu_ms": med(lambda: (ctx.ekf_prediction(1.0, 0.007, 0.007), ctx.sync_stream())),
                              "cpu_oracle_ms": med(lambda: pyoracle.ekf_prediction(frame.x_pred, frame.P_pred, 1.0, 0.007, 0.007), 3)}

@@ -139,7 +139,8 @@ int rslam_fetch_prior   (rslam_ctx* ctx, double* x_pred /* host n, may be NULL *
 
 /* Tracking::matching (Tracking.cpp:279-351): the NCC search between the two segments,
  * on the h / S that rslam_predict left on the device.  image: cam.nRows * cam.nCols uint8, row-major (the
- * cv::Mat of the frame); patches: L * 169 doubles, feature f's predicted 13 x 13 patch
+ * cv::Mat of the frame); patches: NULL = the ones rslam_predict_patches left on the device, else L * 169
+ * doubles, feature f's predicted 13 x 13 patch
  * (features_info[f].patch_when_matching, column-major, written by pred_patch_fc at Tracking.cpp:277;
  * ignored where the feature was not predicted).  Outputs (host): z (L*2) = (column, row) of the best
  * candidate where ic[f] = 1; ic (L) = individually_compatible; corr (L, may be NULL) = best normalised
@@ -148,6 +149,29 @@ int rslam_fetch_prior   (rslam_ctx* ctx, double* x_pred /* host n, may be NULL *
  * threshold 0.80 and gate 5.9915 as at Tracking.cpp:281-283; candidates are visited column by column and
  * the first maximum wins, as Eigen's maxCoeff does (:342). */
 int rslam_match(rslam_ctx* ctx, const uint8_t* image, const double* patches, double* z, uint8_t* ic, double* corr);
+
+/* Tracking::pred_patch_fc (Tracking.cpp:164-278): the 13 x 13 patch every predicted
+ * feature is expected to show, warped from its initialisation record.  The records are what
+ * Map::initialize_a_features stores (Map.cpp:286-292) and live in a device-side feature store:
+ *   rslam_set_feature_records    all L features at once: uv (L*2) = uv_when_initialized, R_wc (L*9, column-major)
+ *                                = R_wc_when_initialized, r_wc (L*3) = r_wc_when_initialized, patches (L*1681) =
+ *                                patch_when_initialized (41 x 41, column-major as Eigen stores it)
+ *   rslam_append_feature_record  one more feature (after rslam_map_add_feature); rslam_map_delete_feature drops
+ *                                the record of the feature it removes
+ *   rslam_predict_patches        after rslam_predict: warps every feature that has a prediction, on x_k_km1 and h
+ *                                resident on the device.  patches (host L*169, column-major 13 x 13 each, may be
+ *                                NULL) = patch_when_matching; status (L, may be NULL): 1 warped, 0 zero patch
+ *                                because h is within half a patch of the image border (Tracking.cpp:174-175,276),
+ *                                2 no prediction, -1 the reference's meshgrid would not be 13 x 13.
+ * The patches stay on the device: rslam_match(ctx, image, NULL, ...) searches with them.
+ * compat = 1 keeps two quirks of the reference: the remap coordinates are one pixel off (MATLAB indices at
+ * Tracking.cpp:263-264) and a Cartesian feature is warped about the world point of the last inverse-depth
+ * feature before it (Tracking.cpp:52-61); compat = 0 corrects both.  cv::remap is restated as OpenCV
+ * documents it for CV_32F sources: 1/32-pixel coordinates, float weights, BORDER_CONSTANT 0. */
+int rslam_set_feature_records  (rslam_ctx* ctx, int32_t L, const double* uv, const double* R_wc, const double* r_wc,
+                                const double* patches);
+int rslam_append_feature_record(rslam_ctx* ctx, const double* uv, const double* R_wc, const double* r_wc, const double* patch);
+int rslam_predict_patches      (rslam_ctx* ctx, double* patches, int32_t* status);
 
 /* Map::map_management's edits of x_k_k / p_k_k on the resident posterior, so
  * that the covariance never leaves HBM between frames.  The host keeps features_info (patches,

@@ -72,6 +72,9 @@ def lib():
         L.orc_add_feature_jacobians.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
         L.orc_matching.argtypes = [C.c_void_p, _u8p, C.c_int, _dp, C.c_int, _dp, _u8p, _dp, _dp, _u8p, _dp, _dp]
         L.orc_matching.restype = None
+        L.orc_pred_patches.argtypes = [C.c_void_p, C.c_int, C.c_int, _u8p, _i32p, _dp, _dp, _u8p, _dp, _dp, _dp, _dp, C.c_int,
+                                       C.c_int, _dp, _i32p, _dp]
+        L.orc_pred_patches.restype = None
         L.orc_ekf_prediction.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         L.orc_motion_model.argtypes = [_dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]
         _lib = L
@@ -354,3 +357,21 @@ def matching(cam, image, patches, h, has_h, S, half=6):
     lib().orc_matching(C.byref(cam), _p(image, _u8p), L, _p(pt), half, _p(h), _p(has_h, _u8p), _p(S), _p(z), _p(ic, _u8p),
                        _p(corr), _p(m))
     return z, ic, corr, m
+
+
+def pred_patches(cam, compat, types, offsets, x, h, has_h, uv_f, R_f, r_f, patch_f, half_f=20, half=6):
+    """Tracking::pred_patch_fc for every feature.  uv_f (L,2); R_f (L,3,3) rotation matrices; r_f (L,3);
+    patch_f (L,41,41) with patch_f[f][row, col]  ->  patches (L,13,13) [row, col], status (L), margins (L)"""
+    L = len(types)
+    sf, so = 2 * half_f + 1, 2 * half + 1
+    types = np.ascontiguousarray(types, np.uint8); offsets = np.ascontiguousarray(offsets, np.int32)
+    x = np.ascontiguousarray(x, np.float64); h = np.ascontiguousarray(np.nan_to_num(h), np.float64)
+    has_h = np.ascontiguousarray(has_h, np.uint8)
+    uv = np.ascontiguousarray(uv_f, np.float64)
+    Rf = np.ascontiguousarray(np.transpose(np.asarray(R_f, np.float64).reshape(L, 3, 3), (0, 2, 1)))      # col-major
+    rf = np.ascontiguousarray(r_f, np.float64)
+    pf = np.ascontiguousarray(np.transpose(np.asarray(patch_f, np.float64).reshape(L, sf, sf), (0, 2, 1)))
+    out = np.zeros((L, so, so)); status = np.zeros(L, np.int32); m = np.zeros(max(L, 1))
+    lib().orc_pred_patches(C.byref(cam), compat, L, _p(types, _u8p), _p(offsets, _i32p), _p(x), _p(h), _p(has_h, _u8p),
+                           _p(uv), _p(Rf), _p(rf), _p(pf), half_f, half, _p(out), _p(status, _i32p), _p(m))
+    return np.transpose(out, (0, 2, 1)).copy(), status, m[:L]

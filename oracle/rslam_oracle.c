@@ -1487,6 +1487,204 @@ void orc_matching(const rslam_camera* cam, const uint8_t* image, int L, const do
 }
 
 /* ------------------------------------------------------------------ */
+/* Patch prediction: Tracking::pred_patch_fc,            */
+/* Tracking.cpp:164-278, called from search_IC_matches :46-65             */
+/* ------------------------------------------------------------------ */
+
+/* fixed-size Matrix4d::inverse(): cofactors over 2 x 2 sub-determinants (col-major in/out) */
+static void inv4_fixed(const double m[16], double r[16])
+{
+#define A(i, j) m[(i) + 4 * (j)]
+    const double s0 = A(0,0) * A(1,1) - A(1,0) * A(0,1), s1 = A(0,0) * A(1,2) - A(1,0) * A(0,2);
+    const double s2 = A(0,0) * A(1,3) - A(1,0) * A(0,3), s3 = A(0,1) * A(1,2) - A(1,1) * A(0,2);
+    const double s4 = A(0,1) * A(1,3) - A(1,1) * A(0,3), s5 = A(0,2) * A(1,3) - A(1,2) * A(0,3);
+    const double c5 = A(2,2) * A(3,3) - A(3,2) * A(2,3), c4 = A(2,1) * A(3,3) - A(3,1) * A(2,3);
+    const double c3 = A(2,1) * A(3,2) - A(3,1) * A(2,2), c2 = A(2,0) * A(3,3) - A(3,0) * A(2,3);
+    const double c1 = A(2,0) * A(3,2) - A(3,0) * A(2,2), c0 = A(2,0) * A(3,1) - A(3,0) * A(2,1);
+    const double id = 1.0 / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+#define R_(i, j) r[(i) + 4 * (j)]
+    R_(0,0) = ( A(1,1) * c5 - A(1,2) * c4 + A(1,3) * c3) * id;
+    R_(0,1) = (-A(0,1) * c5 + A(0,2) * c4 - A(0,3) * c3) * id;
+    R_(0,2) = ( A(3,1) * s5 - A(3,2) * s4 + A(3,3) * s3) * id;
+    R_(0,3) = (-A(2,1) * s5 + A(2,2) * s4 - A(2,3) * s3) * id;
+    R_(1,0) = (-A(1,0) * c5 + A(1,2) * c2 - A(1,3) * c1) * id;
+    R_(1,1) = ( A(0,0) * c5 - A(0,2) * c2 + A(0,3) * c1) * id;
+    R_(1,2) = (-A(3,0) * s5 + A(3,2) * s2 - A(3,3) * s1) * id;
+    R_(1,3) = ( A(2,0) * s5 - A(2,2) * s2 + A(2,3) * s1) * id;
+    R_(2,0) = ( A(1,0) * c4 - A(1,1) * c2 + A(1,3) * c0) * id;
+    R_(2,1) = (-A(0,0) * c4 + A(0,1) * c2 - A(0,3) * c0) * id;
+    R_(2,2) = ( A(3,0) * s4 - A(3,1) * s2 + A(3,3) * s0) * id;
+    R_(2,3) = (-A(2,0) * s4 + A(2,1) * s2 - A(2,3) * s0) * id;
+    R_(3,0) = (-A(1,0) * c3 + A(1,1) * c1 - A(1,2) * c0) * id;
+    R_(3,1) = ( A(0,0) * c3 - A(0,1) * c1 + A(0,2) * c0) * id;
+    R_(3,2) = (-A(3,0) * s3 + A(3,1) * s1 - A(3,2) * s0) * id;
+    R_(3,3) = ( A(2,0) * s3 - A(2,1) * s1 + A(2,2) * s0) * id;
+#undef A
+#undef R_
+}
+
+static void mul3(const double a[9], const double b[9], double c[9])     /* col-major 3 x 3 */
+{
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) c[i + 3 * j] = a[i] * b[3 * j] + a[i + 3] * b[1 + 3 * j] + a[i + 6] * b[2 + 3 * j];
+}
+
+/* "H = [R 0; 0 1] * [I r; 0 1]" of Tracking.cpp:189-194 = [R, R r; 0 1], col-major 4 x 4 */
+static void pose_matrix(const double R[9], const double r[3], double H[16])
+{
+    memset(H, 0, sizeof(double) * 16);
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) H[i + 4 * j] = R[i + 3 * j];
+    for (int i = 0; i < 3; ++i) H[i + 12] = R[i] * r[0] + R[i + 3] * r[1] + R[i + 6] * r[2];
+    H[15] = 1.0;
+}
+
+/* cv::remap(src CV_32F, map1/map2 CV_32FC1, INTER_LINEAR, BORDER_CONSTANT 0) at one point, as OpenCV
+ * does it: coordinates quantised to 1/32 pixel (cvRound(x * INTER_TAB_SIZE), round half to even), the
+ * four weights from the float table (1 - a)(1 - b) ..., float accumulation in tap order.  src is the
+ * sh x sw row-major float image. */
+/* distance (pixels) of a double map coordinate from the point where its float32 cast would flip */
+static double f32_cast_margin(double v)
+{
+    const float f = (float)v;
+    const double err = fabs(v - (double)f);
+    const double up = fabs((double)nextafterf(f, INFINITY) - (double)f), dn = fabs((double)f - (double)nextafterf(f, -INFINITY));
+    const double half_ulp = 0.5 * (up < dn ? up : dn);
+    return half_ulp - err;
+}
+
+static float remap_bilinear_f32(const float* src, int sh, int sw, float mapx, float mapy)
+{
+    /* after the float cast everything below is exact integer / float arithmetic, identical wherever it runs */
+    const double qx = (double)mapx * 32.0, qy = (double)mapy * 32.0;
+    const int sx = (int)nearbyint(qx), sy = (int)nearbyint(qy);
+    const int ix = sx >> 5, iy = sy >> 5;           /* arithmetic shift = floor */
+    const float fx = (float)(sx & 31) / 32.f, fy = (float)(sy & 31) / 32.f;
+    const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
+    float v[4];
+    for (int k = 0; k < 4; ++k) {
+        const int x = ix + (k & 1), y = iy + (k >> 1);
+        v[k] = (x >= 0 && x < sw && y >= 0 && y < sh) ? src[(size_t)y * sw + x] : 0.f;
+    }
+    return v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11;
+}
+
+/* One feature.  xv: camera state r(3) q(4) of x_k_km1; h: predicted pixel; uv_f, R_f (col-major), r_f,
+ * patch_f (side_f x side_f col-major, side_f = 2 * half_f + 1): the feature's initialisation record;
+ * XYZ_w: the world point handed in by search_IC_matches.  out: 13 x 13 col-major.
+ * compat = 1 keeps the reference's one-pixel offset of the remap coordinates (MATLAB 1-based indices,
+ * Tracking.cpp:263-264); compat = 0 removes it.  Returns 1 when a patch was warped, 0 when h is too close
+ * to the border (zero patch, :174-175,276), -1 when the meshgrid would not be 13 x 13.  *margin (nullable) is
+ * lowered to the smallest distance of a map coordinate from a flip of its float32 cast and of the patch centre
+ * from an integer (the cv::Range truncation) -- the two steps at which two correct double-precision evaluations
+ * of the geometry can end in different patches. */
+int orc_pred_patch(const rslam_camera* cam, int compat, const double xv[7], const double h[2], const double uv_f[2],
+                   const double R_f[9], const double r_f[3], const double* patch_f, int half_f, const double XYZ_w[3],
+                   int half, double* out, double* margin)
+{
+    const int side = 2 * half + 1, side_f = 2 * half_f + 1;
+    memset(out, 0, sizeof(double) * (size_t)side * side);
+    if (!((h[0] > half) && (h[0] < cam->nCols - half) && (h[1] > half) && (h[1] < cam->nRows - half))) return 0;
+    const double f = cam->f, dx = cam->dx, cx = cam->Cx, cy = cam->Cy;
+    double R_wc[9];
+    orc_q2r(xv + 3, R_wc);
+    double H_f[16], H_k[16], H_f_inv[16], Hr[16];
+    pose_matrix(R_f, r_f, H_f);
+    pose_matrix(R_wc, xv, H_k);
+    inv4_fixed(H_f, H_f_inv);
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            double a = 0;
+            for (int k = 0; k < 4; ++k) a += H_f_inv[i + 4 * k] * H_k[k + 4 * j];
+            Hr[i + 4 * j] = a;                                            /* H_kpf_k */
+        }
+    /* plane normal, :196-209 */
+    double n1[3] = { uv_f[0] - cx, uv_f[1] - cy, -f / dx };
+    double nn = sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    for (int a = 0; a < 3; ++a) n1[a] = n1[a] / nn;
+    const double n2in[4] = { h[0] - cx, h[1] - cy, -f / dx, 1.0 };
+    double n2[4];
+    for (int i = 0; i < 4; ++i) n2[i] = Hr[i] * n2in[0] + Hr[i + 4] * n2in[1] + Hr[i + 8] * n2in[2] + Hr[i + 12] * n2in[3];
+    for (int i = 0; i < 4; ++i) n2[i] = n2[i] / n2[3];      /* n_temp / n_temp(3): element 3 divided last, it is 1 afterwards */
+    nn = sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
+    double n[3];
+    for (int a = 0; a < 3; ++a) n[a] = n1[a] + n2[a] / nn;
+    nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int a = 0; a < 3; ++a) n[a] = n[a] / nn;
+    /* plane offset, :211-217 */
+    double X[4];
+    for (int i = 0; i < 4; ++i) X[i] = H_f_inv[i] * XYZ_w[0] + H_f_inv[i + 4] * XYZ_w[1] + H_f_inv[i + 8] * XYZ_w[2] + H_f_inv[i + 12];
+    for (int i = 0; i < 4; ++i) X[i] = X[i] / X[3];
+    const double d = -(n[0] * X[0] + n[1] * X[1] + n[2] * X[2]);
+    /* homography M = K (R - t n'/d) K^-1 and its inverse, :226,247 */
+    const double K[9] = { f / dx, 0, 0,  0, f / cam->dy, 0,  cx, cy, 1 };
+    double Kinv[9], G[9], T1[9], M[9], Minv[9];
+    inv3_fixed(K, Kinv);
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) G[i + 3 * j] = Hr[i + 4 * j] - Hr[i + 12] * n[j] / d;
+    mul3(K, G, T1);
+    mul3(T1, Kinv, M);
+    inv3_fixed(M, Minv);
+    /* centre of the predicted patch in the current image, :221-236 */
+    double c1u[2], t3[3], c2u[2], c2[2];
+    orc_undistort_fm(cam, uv_f, c1u);
+    for (int i = 0; i < 3; ++i) t3[i] = Minv[i] * c1u[0] + Minv[i + 3] * c1u[1] + Minv[i + 6];
+    c2u[0] = t3[0] / t3[2]; c2u[1] = t3[1] / t3[2];
+    orc_distort_fm(cam, c2u, c2);
+    /* cv::Range(double, double): truncation towards zero, :239-240 */
+    const int xs = (int)(c2[0] - half), xe = (int)(c2[0] + half), ys = (int)(c2[1] - half), ye = (int)(c2[1] + half);
+    if (xe - xs + 1 != side || ye - ys + 1 != side) return -1;
+    if (margin) {            /* the truncations above are the other discontinuity: distance of the centre from an integer */
+        const double mu_ = fabs(c2[0] - nearbyint(c2[0])), mv_ = fabs(c2[1] - nearbyint(c2[1]));
+        if (mu_ < *margin) *margin = mu_;
+        if (mv_ < *margin) *margin = mv_;
+    }
+    float* src = (float*)malloc(sizeof(float) * (size_t)side_f * side_f);
+    for (int r = 0; r < side_f; ++r)
+        for (int c = 0; c < side_f; ++c) src[(size_t)r * side_f + c] = (float)patch_f[r + (size_t)side_f * c];
+    const double off = compat ? (double)(half_f + 1) : (double)half_f;
+    for (int j = 0; j < side; ++j)              /* column of the output = u */
+        for (int i = 0; i < side; ++i) {        /* row = v */
+            const double p[2] = { (double)(xs + j), (double)(ys + i) };
+            double pu[2], q3[3], qu[2], qd[2];
+            orc_undistort_fm(cam, p, pu);
+            for (int a = 0; a < 3; ++a) q3[a] = M[a] * pu[0] + M[a + 3] * pu[1] + M[a + 6];
+            qu[0] = q3[0] / q3[2]; qu[1] = q3[1] / q3[2];
+            orc_distort_fm(cam, qu, qd);
+            const double mu = qd[0] - (uv_f[0] - off), mv = qd[1] - (uv_f[1] - off);
+            if (margin) {
+                const double m1 = f32_cast_margin(mu), m2 = f32_cast_margin(mv);
+                if (m1 < *margin) *margin = m1;
+                if (m2 < *margin) *margin = m2;
+            }
+            out[i + (size_t)side * j] = (double)remap_bilinear_f32(src, side_f, side_f, (float)mu, (float)mv);
+        }
+    free(src);
+    return 1;
+}
+
+/* The loop of Tracking::search_IC_matches, :46-65.  The reference refreshes XYZ_w only for inverse-depth
+ * features; a Cartesian feature is warped with the point of the last inverse-depth feature before it
+ * (compat = 1; zeros when there is none, where the reference reads an uninitialised vector); compat = 0
+ * uses the feature's own coordinates.  status (L): result of orc_pred_patch, 2 = no prediction. */
+void orc_pred_patches(const rslam_camera* cam, int compat, int L, const uint8_t* type, const int32_t* offset,
+                      const double* x, const double* h, const uint8_t* has_h, const double* uv_f, const double* R_f,
+                      const double* r_f, const double* patch_f, int half_f, int half, double* out, int32_t* status,
+                      double* margin /* L, nullable: per feature */)
+{
+    const int side = 2 * half + 1, side_f = 2 * half_f + 1;
+    double XYZ_w[3] = {0, 0, 0};
+    for (int i = 0; i < L; ++i) {
+        if (type[i] == RSLAM_FEAT_INVERSE_DEPTH) inversedepth2cartesian(x + offset[i], XYZ_w);
+        else if (!compat) { XYZ_w[0] = x[offset[i]]; XYZ_w[1] = x[offset[i] + 1]; XYZ_w[2] = x[offset[i] + 2]; }
+        double* o = out + (size_t)i * side * side;
+        if (margin) margin[i] = 1e300;
+        if (!has_h[i]) { status[i] = 2; memset(o, 0, sizeof(double) * (size_t)side * side); continue; }
+        status[i] = orc_pred_patch(cam, compat, x, h + 2 * i, uv_f + 2 * i, R_f + 9 * i, r_f + 3 * i,
+                                   patch_f + (size_t)i * side_f * side_f, half_f, XYZ_w, half, o, margin ? margin + i : NULL);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* introspection                                                        */
 /* ------------------------------------------------------------------ */
 

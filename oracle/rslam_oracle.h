@@ -110,6 +110,14 @@ int  orc_match_feature(const rslam_camera* cam, const uint8_t* image, const doub
 void orc_matching(const rslam_camera* cam, const uint8_t* image, int L, const double* patches, int half,
                   const double* h, const uint8_t* has_h, const double* S, double* z, uint8_t* ic, double* corr,
                   double margins[3]);
+/* Patch prediction: Tracking::pred_patch_fc, Tracking.cpp:164-278 and its caller :46-65 */
+int  orc_pred_patch(const rslam_camera* cam, int compat, const double xv[7], const double h[2], const double uv_f[2],
+                    const double R_f[9], const double r_f[3], const double* patch_f, int half_f, const double XYZ_w[3],
+                    int half, double* out, double* margin);
+void orc_pred_patches(const rslam_camera* cam, int compat, int L, const uint8_t* type, const int32_t* offset,
+                      const double* x, const double* h, const uint8_t* has_h, const double* uv_f, const double* R_f,
+                      const double* r_f, const double* patch_f, int half_f, int half, double* out, int32_t* status,
+                      double* margin);
 /* dynamic-size inverse as Eigen does it (PartialPivLU), Tracking.cpp:421 */
 int  orc_inverse_lu(int n, const double* A, double* Ainv);
 

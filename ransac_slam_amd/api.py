@@ -32,6 +32,9 @@ SYMBOLS = {
     "rslam_ekf_prediction": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "rslam_fetch_prior": (C.c_int, [C.c_void_p, _dp, _dp]),
     "rslam_match": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _u8p, _dp]),
+    "rslam_set_feature_records": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp]),
+    "rslam_append_feature_record": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "rslam_predict_patches": (C.c_int, [C.c_void_p, _dp, _i32p]),
     "rslam_map_delete_feature": (C.c_int, [C.c_void_p, C.c_int32]),
     "rslam_map_convert": (C.c_int, [C.c_void_p, C.c_double, _i32p, _dp]),
     "rslam_map_add_feature": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
@@ -150,13 +153,43 @@ class RslamHip:
         _chk(lib().rslam_ekf_prediction(self._h, delta_t, std_a, std_alpha), "rslam_ekf_prediction")
 
     # ---- Tracking::matching on the resident prediction ---------------------
-    def match(self, image, patches):
-        """image (nRows, nCols) uint8; patches (L, 13, 13) with patches[f][row, col] -> z (L,2), ic (L), corr (L)"""
+    def match(self, image, patches=None):
+        """image (nRows, nCols) uint8; patches (L, 13, 13) with patches[f][row, col], or None for the ones
+        predict_patches() left on the device -> z (L,2), ic (L), corr (L)"""
         image = np.ascontiguousarray(image, np.uint8)
-        pt = np.ascontiguousarray(np.transpose(np.asarray(patches, np.float64).reshape(self.L, 13, 13), (0, 2, 1)))
+        pt = None
+        if patches is not None:
+            pt = np.ascontiguousarray(np.transpose(np.asarray(patches, np.float64).reshape(self.L, 13, 13), (0, 2, 1)))
         z = np.zeros((max(self.L, 1), 2)); ic = np.zeros(max(self.L, 1), np.uint8); corr = np.zeros(max(self.L, 1))
-        _chk(lib().rslam_match(self._h, _p(image, _u8p), _p(pt), _p(z), _p(ic, _u8p), _p(corr)), "rslam_match")
+        _chk(lib().rslam_match(self._h, _p(image, _u8p), _p(pt) if pt is not None else None, _p(z), _p(ic, _u8p), _p(corr)),
+             "rslam_match")
         return z[:self.L], ic[:self.L], corr[:self.L]
+
+    # ---- Tracking::pred_patch_fc and its feature store ------------------------
+    @staticmethod
+    def _records(uv_f, R_f, r_f, patch_f):
+        uv = np.ascontiguousarray(uv_f, np.float64).reshape(-1, 2)
+        n = len(uv)
+        Rf = np.ascontiguousarray(np.transpose(np.asarray(R_f, np.float64).reshape(n, 3, 3), (0, 2, 1)))      # column-major
+        rf = np.ascontiguousarray(r_f, np.float64).reshape(n, 3)
+        pf = np.ascontiguousarray(np.transpose(np.asarray(patch_f, np.float64).reshape(n, 41, 41), (0, 2, 1)))
+        return n, uv, Rf, rf, pf
+
+    def set_feature_records(self, uv_f, R_f, r_f, patch_f):
+        """uv_f (L,2); R_f (L,3,3); r_f (L,3); patch_f (L,41,41) with patch_f[f][row, col]"""
+        n, uv, Rf, rf, pf = self._records(uv_f, R_f, r_f, patch_f)
+        _chk(lib().rslam_set_feature_records(self._h, n, _p(uv), _p(Rf), _p(rf), _p(pf)), "rslam_set_feature_records")
+
+    def append_feature_record(self, uv_f, R_f, r_f, patch_f):
+        _, uv, Rf, rf, pf = self._records(uv_f, R_f, r_f, patch_f)
+        _chk(lib().rslam_append_feature_record(self._h, _p(uv), _p(Rf), _p(rf), _p(pf)), "rslam_append_feature_record")
+
+    def predict_patches(self, fetch=True):
+        """-> patches (L,13,13) [row, col] (None when fetch is False), status (L)"""
+        out = np.zeros((max(self.L, 1), 13, 13)) if fetch else None
+        st = np.zeros(max(self.L, 1), np.int32)
+        _chk(lib().rslam_predict_patches(self._h, _p(out) if fetch else None, _p(st, _i32p)), "rslam_predict_patches")
+        return (np.transpose(out[:self.L], (0, 2, 1)).copy() if fetch else None), st[:self.L]
 
     # ---- Map::map_management state surgery on the resident posterior -------
     def get_layout(self):

@@ -96,6 +96,9 @@ void launch_map_linearity(hipStream_t s, const double* x, const double* P, int N
 void launch_match(hipStream_t s, const Cam& cam, const uint8_t* image, const double* patches, int L, const double* h,
                   const uint8_t* has_h, const double* S, double corr_threshold, double chi2, double* z, uint8_t* ic,
                   double* corr);
+void launch_pred_patches(hipStream_t s, const Cam& cam, int compat, int L, const uint8_t* type, const int32_t* off,
+                         const int32_t* xyz_src, const double* x, const double* h, const uint8_t* has_h,
+                         const int32_t* slot, const double* rec, const float* rec_patch, double* out, int32_t* status);
 int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kernels (80 KiB)
 int init_kernel_attributes2();
 void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,

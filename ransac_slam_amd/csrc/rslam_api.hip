@@ -75,6 +75,13 @@ struct rslam_ctx {
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Linv,
                    d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr;
     DevBuf<uint8_t> d_image;
+    // feature store: initialisation records of Map::initialize_a_features (Map.cpp:286-292), one slot per feature
+    DevBuf<double> d_rec;                 // slot * 14: uv(2) R(9 col-major) r(3)
+    DevBuf<float> d_rec_patch;            // slot * 1681: patch_when_initialized as float32, row-major 41 x 41
+    DevBuf<int32_t> d_slot, d_xyz_src, d_pstatus;
+    std::vector<int32_t> h_slot, free_slots;
+    int store_cap = 0;
+    bool patches_valid = false;           // d_patches holds the output of rslam_predict_patches for the current prediction
     DevBuf<int32_t> d_first;
     // timing
     int timing = 0;
@@ -169,6 +176,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release();
+    c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -361,7 +369,7 @@ static int enqueue_predict(rslam_ctx* c)
                    c->d_h.p, c->d_hash.p, c->d_vis.p, c->d_H13.p, c->d_S.p, 1.0 /* features_info[i].R = I, Map.cpp:310 */,
                    c->d_sel.p);
     mark(c, EV_PREDICT);
-    c->predicted = true; c->pht_done = false; c->dedup_done = false;
+    c->predicted = true; c->pht_done = false; c->dedup_done = false; c->patches_valid = false;
     return RSLAM_OK;
 }
 
@@ -593,16 +601,21 @@ extern "C" int rslam_predict(rslam_ctx* c, const rslam_layout* layout, const dou
 // ------------------------------------------------------------------------
 extern "C" int rslam_match(rslam_ctx* c, const uint8_t* image, const double* patches, double* z, uint8_t* ic, double* corr)
 {
-    if (!c || !image || !patches || !z || !ic) return RSLAM_ERR_ARG;
+    if (!c || !image || !z || !ic) return RSLAM_ERR_ARG;
     if (!c->have_state || !c->predicted) return RSLAM_ERR_STATE;
+    if (!patches && !c->patches_valid) return RSLAM_ERR_STATE;      // NULL = the patches rslam_predict_patches left on the device
     HIPCHK(hipSetDevice(c->device));
     const int L = c->L;
     if (L == 0) return RSLAM_OK;
     const size_t npix = (size_t)c->cam.nRows * c->cam.nCols;
-    if (c->d_image.ensure(npix) < 0 || c->d_patches.ensure((size_t)L * 169) < 0 || c->d_corr.ensure(L) < 0) return RSLAM_ERR_HIP;
+    if (c->d_image.ensure(npix) < 0 || c->d_corr.ensure(L) < 0) return RSLAM_ERR_HIP;
+    if (patches && c->d_patches.ensure((size_t)L * 169) < 0) return RSLAM_ERR_HIP;
     hipStream_t s = c->stream;
     HIPCHK(hipMemcpyAsync(c->d_image.p, image, npix, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->d_patches.p, patches, sizeof(double) * (size_t)L * 169, hipMemcpyHostToDevice, s));
+    if (patches) {
+        HIPCHK(hipMemcpyAsync(c->d_patches.p, patches, sizeof(double) * (size_t)L * 169, hipMemcpyHostToDevice, s));
+        c->patches_valid = false;
+    }
     HIPCHK(hipMemsetAsync(c->d_z.p, 0, sizeof(double) * 2 * L, s));
     launch_match(s, c->cam, c->d_image.p, c->d_patches.p, L, c->d_h.p, c->d_hash.p, c->d_S.p, 0.80 /* Tracking.cpp:281 */,
                  5.9915 /* :283 */, c->d_z.p, c->d_ic.p, c->d_corr.p);
@@ -611,6 +624,113 @@ extern "C" int rslam_match(rslam_ctx* c, const uint8_t* image, const double* pat
     HIPCHK(hipMemcpyAsync(ic, c->d_ic.p, L, hipMemcpyDeviceToHost, s));
     if (corr) HIPCHK(hipMemcpyAsync(corr, c->d_corr.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// Tracking::pred_patch_fc on the resident prior and the feature store it reads
+// ------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+int grow_keep(DevBuf<T>& b, size_t old_count, size_t new_count, hipStream_t s)
+{
+    if (new_count <= b.cap && b.p) return 0;
+    T* np = nullptr;
+    if (hipMalloc((void**)&np, new_count * sizeof(T)) != hipSuccess) return -1;
+    if (b.p && old_count) {
+        if (hipMemcpyAsync(np, b.p, old_count * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess) { (void)hipFree(np); return -1; }
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(np); return -1; }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np; b.cap = new_count;
+    return 1;
+}
+
+int store_write(rslam_ctx* c, int slot, const double* uv, const double* R, const double* r, const double* patch)
+{
+    double rec[14];
+    rec[0] = uv[0]; rec[1] = uv[1];
+    for (int k = 0; k < 9; ++k) rec[2 + k] = R[k];
+    for (int k = 0; k < 3; ++k) rec[11 + k] = r[k];
+    std::vector<float> pf(1681);
+    for (int rr = 0; rr < 41; ++rr)
+        for (int cc = 0; cc < 41; ++cc) pf[(size_t)rr * 41 + cc] = (float)patch[rr + 41 * cc];       // toCvMat_f, Converter.cpp:83-94
+    HIPCHK(hipMemcpyAsync(c->d_rec.p + (size_t)slot * 14, rec, sizeof(rec), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_rec_patch.p + (size_t)slot * 1681, pf.data(), sizeof(float) * 1681, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                       // the staging buffers are on this stack frame
+    return RSLAM_OK;
+}
+
+int store_reserve(rslam_ctx* c, int slots)
+{
+    if (slots <= c->store_cap) return RSLAM_OK;
+    int cap = c->store_cap ? c->store_cap : 64;
+    while (cap < slots) cap *= 2;
+    if (grow_keep(c->d_rec, (size_t)c->store_cap * 14, (size_t)cap * 14, c->stream) < 0) return RSLAM_ERR_HIP;
+    if (grow_keep(c->d_rec_patch, (size_t)c->store_cap * 1681, (size_t)cap * 1681, c->stream) < 0) return RSLAM_ERR_HIP;
+    for (int k = cap - 1; k >= c->store_cap; --k) c->free_slots.push_back(k);
+    c->store_cap = cap;
+    return RSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" int rslam_append_feature_record(rslam_ctx* c, const double* uv, const double* R_wc, const double* r_wc, const double* patch)
+{
+    if (!c || !uv || !R_wc || !r_wc || !patch) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = store_reserve(c, (int)c->h_slot.size() + 1);
+    if (rc) return rc;
+    const int slot = c->free_slots.back();
+    rc = store_write(c, slot, uv, R_wc, r_wc, patch);
+    if (rc) return rc;
+    c->free_slots.pop_back();
+    c->h_slot.push_back(slot);
+    c->patches_valid = false;
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_set_feature_records(rslam_ctx* c, int32_t L, const double* uv, const double* R_wc, const double* r_wc, const double* patches)
+{
+    if (!c || L < 0 || (L > 0 && (!uv || !R_wc || !r_wc || !patches))) return RSLAM_ERR_ARG;
+    for (int32_t s : c->h_slot) c->free_slots.push_back(s);
+    c->h_slot.clear();
+    for (int i = 0; i < L; ++i) {
+        const int rc = rslam_append_feature_record(c, uv + 2 * (size_t)i, R_wc + 9 * (size_t)i, r_wc + 3 * (size_t)i, patches + 1681 * (size_t)i);
+        if (rc) return rc;
+    }
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_predict_patches(rslam_ctx* c, double* patches, int32_t* status)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_state || !c->predicted) return RSLAM_ERR_STATE;
+    const int L = c->L;
+    if ((int)c->h_slot.size() != L) return RSLAM_ERR_STATE;        // one record per feature (append after rslam_map_add_feature)
+    if (L == 0) return RSLAM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_slot.ensure(L) < 0 || c->d_xyz_src.ensure(L) < 0 || c->d_pstatus.ensure(L) < 0 || c->d_patches.ensure((size_t)L * 169) < 0)
+        return RSLAM_ERR_HIP;
+    // search_IC_matches refreshes XYZ_w for inverse-depth features only (Tracking.cpp:52-61): in compat mode a
+    // Cartesian feature is warped with the point of the last inverse-depth feature before it
+    std::vector<int32_t> src((size_t)L);
+    int last_id = -1;
+    for (int i = 0; i < L; ++i) {
+        if (c->h_type[i] == RSLAM_FEAT_INVERSE_DEPTH) { last_id = i; src[i] = i; }
+        else src[i] = c->cfg.compat ? last_id : i;
+    }
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_slot.p, c->h_slot.data(), sizeof(int32_t) * L, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_xyz_src.p, src.data(), sizeof(int32_t) * L, hipMemcpyHostToDevice, s));
+    launch_pred_patches(s, c->cam, c->cfg.compat, L, c->d_type.p, c->d_off.p, c->d_xyz_src.p, c->d_xpred.p, c->d_h.p, c->d_hash.p,
+                        c->d_slot.p, c->d_rec.p, c->d_rec_patch.p, c->d_patches.p, c->d_pstatus.p);
+    HIPCHK(hipGetLastError());
+    if (patches) HIPCHK(hipMemcpyAsync(patches, c->d_patches.p, sizeof(double) * (size_t)L * 169, hipMemcpyDeviceToHost, s));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->d_pstatus.p, sizeof(int32_t) * L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));                               // src / h_slot staging and the outputs
+    c->patches_valid = true;
     return RSLAM_OK;
 }
 
@@ -713,6 +833,10 @@ extern "C" int rslam_map_delete_feature(rslam_ctx* c, int32_t feature)
     const int w = c->h_type[feature] == RSLAM_FEAT_INVERSE_DEPTH ? 6 : 3;
     std::vector<uint8_t> type(c->h_type);
     type.erase(type.begin() + feature);
+    if ((int)c->h_slot.size() == c->L) {                           // the feature store follows features_info.erase (Map.cpp:27)
+        c->free_slots.push_back(c->h_slot[feature]);
+        c->h_slot.erase(c->h_slot.begin() + feature);
+    }
     return apply_map_edit(c, 0, c->h_off[feature], 0, w, 0, 0, type, 0, 0.0, 0.0, 0.0, 0.0);
 }
 

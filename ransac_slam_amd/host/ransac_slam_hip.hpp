@@ -62,6 +62,11 @@ struct Feature {
     VectorXd h;                          // 2 entries when predicted visible, empty otherwise
     MatrixXd S;                          // 2 x 2
     MatrixXd patch_when_matching;        // 13 x 13, written by pred_patch_fc (Tracking.cpp:277)
+    // initialisation record (Map.cpp:286-292), mirrored into the device-side feature store
+    MatrixXd patch_when_initialized;     // 41 x 41
+    MatrixXd R_wc_when_initialized;      // 3 x 3
+    VectorXd r_wc_when_initialized;      // 3
+    VectorXd uv_when_initialized;        // 2
 };
 
 // ExtendKF members and methods on the hot path (ExtendKF.h:154-169)
@@ -172,10 +177,43 @@ public:
         }
     }
 
+    // The loop over pred_patch_fc in Tracking::search_IC_matches (Tracking.cpp:46-65, :164-278): every
+    // predicted feature's 13 x 13 patch, warped on the device from the feature store.  upload_records = true
+    // (re)sends every feature's initialisation record first; afterwards Map::add_a_feature /
+    // delete_a_feature keep the store in step.  With fetch = false the patches stay on the device for
+    // matching(image, true).
+    void pred_patches(bool upload_records, bool fetch = true)
+    {
+        ExtendKF& k = *mT_ExtendKF;
+        const int L = (int)k.features_info.size();
+        int rc;
+        if (upload_records) {
+            std::vector<double> uv(2 * (size_t)L + 1), R(9 * (size_t)L + 1), r(3 * (size_t)L + 1), pf(1681 * (size_t)L + 1);
+            for (int i = 0; i < L; ++i) {
+                const Feature& f = k.features_info[i];
+                std::memcpy(&uv[2 * (size_t)i], f.uv_when_initialized.data(), sizeof(double) * 2);
+                std::memcpy(&R[9 * (size_t)i], f.R_wc_when_initialized.data(), sizeof(double) * 9);
+                std::memcpy(&r[3 * (size_t)i], f.r_wc_when_initialized.data(), sizeof(double) * 3);
+                std::memcpy(&pf[1681 * (size_t)i], f.patch_when_initialized.data(), sizeof(double) * 1681);
+            }
+            rc = rslam_set_feature_records(k.ctx(), L, uv.data(), R.data(), r.data(), pf.data());
+            if (rc) throw Error(rc, "rslam_set_feature_records");
+        }
+        std::vector<double> patches(fetch ? 169 * (size_t)L + 1 : 1);
+        rc = rslam_predict_patches(k.ctx(), fetch ? patches.data() : nullptr, nullptr);
+        if (rc) throw Error(rc, "rslam_predict_patches");
+        if (fetch)
+            for (int i = 0; i < L; ++i) {
+                MatrixXd& pm = k.features_info[i].patch_when_matching;
+                pm.resize(13, 13);
+                std::memcpy(pm.data(), &patches[169 * (size_t)i], sizeof(double) * 169);
+            }
+    }
+
     // Tracking::matching (Tracking.cpp:279-351): the NCC search on the device, on the h / S that
     // search_IC_matches_predict left there.  image = the frame's cv::Mat data (uint8, nRows x nCols,
     // row-major); the predicted patches come from pred_patch_fc, which stays on the host.
-    void matching(const uint8_t* image)
+    void matching(const uint8_t* image, bool patches_on_device = false)
     {
         ExtendKF& k = *mT_ExtendKF;
         const int L = (int)k.features_info.size();
@@ -185,7 +223,7 @@ public:
             const MatrixXd& pm = k.features_info[i].patch_when_matching;
             if (pm.rows() == 13 && pm.cols() == 13) std::memcpy(&patches[(size_t)i * 169], pm.data(), sizeof(double) * 169);
         }
-        const int rc = rslam_match(k.ctx(), image, patches.data(), z.data(), ic.data(), nullptr);
+        const int rc = rslam_match(k.ctx(), image, patches_on_device ? nullptr : patches.data(), z.data(), ic.data(), nullptr);
         if (rc) throw Error(rc, "rslam_match");
         for (int i = 0; i < L; ++i) {
             Feature& f = k.features_info[i];
@@ -280,13 +318,21 @@ public:
 
     // Fourth step of Map::initialize_a_features (Map.cpp:271-312): hinv, the covariance of the new
     // feature (add_a_feature_covariance_inverse_depth, Map.cpp:339-400) and its features_info entry
-    void add_a_feature(const double uv[2], int initial_rho = 1, int std_rho = 1)
+    // new_feature carries the image-side fields the host filled (patch_when_initialized, uv_when_initialized,
+    // R_wc / r_wc_when_initialized, Map.cpp:286-292); when all four are set its record goes to the feature store
+    void add_a_feature(const double uv[2], Feature new_feature = Feature(), int initial_rho = 1, int std_rho = 1)
     {
-        const int rc = rslam_map_add_feature(mM_ExtendKF->ctx(), uv, initial_rho, std_rho);
+        int rc = rslam_map_add_feature(mM_ExtendKF->ctx(), uv, initial_rho, std_rho);
         if (rc) throw Error(rc, "rslam_map_add_feature");
-        Feature f;
-        f.type = "inversedepth";
-        mM_ExtendKF->features_info.push_back(f);
+        new_feature.type = "inversedepth";
+        if (new_feature.patch_when_initialized.rows() == 41 && new_feature.R_wc_when_initialized.rows() == 3 &&
+            new_feature.r_wc_when_initialized.rows() == 3 && new_feature.uv_when_initialized.rows() == 2) {
+            rc = rslam_append_feature_record(mM_ExtendKF->ctx(), new_feature.uv_when_initialized.data(),
+                                             new_feature.R_wc_when_initialized.data(), new_feature.r_wc_when_initialized.data(),
+                                             new_feature.patch_when_initialized.data());
+            if (rc) throw Error(rc, "rslam_append_feature_record");
+        }
+        mM_ExtendKF->features_info.push_back(new_feature);
     }
 
 private:

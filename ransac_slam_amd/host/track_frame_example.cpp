@@ -72,7 +72,7 @@ int main(int argc, char** argv)
             const int converted = map.inversedepth_2_cartesian(1e-30);   // nothing is that linear: no edit
             const size_t visible = map.predicted_positions().size();
             const double uv[2] = {140.0, 100.0};
-            map.add_a_feature(uv);
+            map.add_a_feature(uv);                                   // no image-side record here: state surgery only
             std::vector<uint8_t> t2; std::vector<int32_t> o2;
             int off = 13;
             for (const Feature& ft : kf.features_info) {

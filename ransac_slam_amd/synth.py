@@ -194,3 +194,28 @@ def make_match_inputs(cam, h, visible, seed=0, offset_px=2.0, noise=3.0, frac_un
         patches[f] = image[y - 6:y + 7, x - 6:x + 7] + rng.normal(0.0, noise, (13, 13))
         truth[f] = (x, y)
     return image, patches, truth
+
+
+def make_feature_records(cam, fr, seed=0, pose_jitter=0.02):
+    """Initialisation records of every feature as Map::initialize_a_features stores them
+    (Map.cpp:286-292): uv_when_initialized, R_wc / r_wc_when_initialized of a camera pose near the
+    current one (so that the homography of pred_patch_fc stays close to the identity) and a smooth
+    random 41 x 41 patch_when_initialized.  Returns uv_f (L,2), R_f (L,3,3), r_f (L,3), patch_f (L,41,41)."""
+    rng = np.random.default_rng(SEED_BASE + 0x51AB0000 + seed)
+    L = fr.L
+    uv_f = np.zeros((L, 2)); R_f = np.zeros((L, 3, 3)); r_f = np.zeros((L, 3)); patch_f = np.zeros((L, 41, 41))
+    k = np.array([1.0, 4.0, 6.0, 4.0, 1.0]); k /= k.sum()
+    for i in range(L):
+        x0 = fr.x_pred.copy()
+        x0[0:3] += rng.normal(0, pose_jitter, 3)
+        q = x0[3:7] + rng.normal(0, pose_jitter * 0.5, 4)
+        x0[3:7] = q / np.linalg.norm(q)
+        uv = project(cam, x0, fr.types[i:i + 1], fr.offsets[i:i + 1])[0]
+        uv_f[i] = np.round(np.clip(uv, [25, 25], [cam.nCols - 26, cam.nRows - 26]))     # FAST corners are integer pixels
+        R_f[i] = q2r(x0[3:7]); r_f[i] = x0[0:3]
+        base = rng.normal(0.0, 1.0, (49, 49))
+        for ax in (0, 1):
+            base = sum(np.roll(base, s - 2, axis=ax) * k[s] for s in range(5))
+        base = base[4:-4, 4:-4]
+        patch_f[i] = np.clip(128.0 + 60.0 * base / base.std(), 0, 255).astype(np.uint8)   # toMatrixd_atuc of an image crop
+    return uv_f, R_f, r_f, patch_f
