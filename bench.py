@@ -158,7 +158,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(2):                             # let the sweep launch sizing settle (needs a sync)
+    for _ in range(10):                            # let the sweep launch sizing settle (it adapts at syncs)
         step()
         ctx.sync()
     for _ in range(args.warmup):

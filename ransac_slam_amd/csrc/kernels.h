@@ -75,9 +75,10 @@ void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel,
 // K == 0: C = Pin exactly (ExtendKF.cpp:635-638 pass-through)
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                        const int32_t* tile_order /* nullable: row-major triangle */);
+                        const int32_t* tile_order /* nullable: row-major triangle */,
+                        const double* Tq /* nullable: 4 x 4 Jnorm, applied to rows/columns 3..6 (K11) when sel[slot_k] != 0 */,
+                        int slot_k);
 void make_rank_update_order(int nT, std::vector<int32_t>& order);   // XCD-aware (bi << 16 | bj) per block
-void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_k, const double* T, double* P);
 
 // x_pred[0:13], FQ (338 doubles) and the 13-row/column strips of P_pred; the caller copies
 // x[13:] and P beforehand

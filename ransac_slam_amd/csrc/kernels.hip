@@ -1109,8 +1109,8 @@ void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * r
 // division => 1/|q|^2 in compat mode).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, const double* __restrict__ A,
-               const double* __restrict__ x_in, double* __restrict__ x_out)
+xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, int slot_k, const double* __restrict__ A,
+               const double* __restrict__ x_in, double* __restrict__ x_out, double* __restrict__ T, int compat)
 {
     // 16 rows x 16 K-slices per workgroup; fixed-order LDS reduction (bitwise reproducible)
     __shared__ double part[16][17];
@@ -1129,30 +1129,29 @@ xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, con
         for (int q = 0; q < 16; ++q) ssum += part[q][r];
         x_out[row] = x_in[row] + ssum;
     }
-}
-
-__global__ void quat_kernel(const int32_t* __restrict__ sel, int slot_k, double* __restrict__ x, double* __restrict__ T,
-                            int compat)
-{
+    // the quaternion lives in rows 3..6 of workgroup 0: normalisation and Jnorm ride along
+    if (blockIdx.x != 0) return;
+    __threadfence_block();
+    __syncthreads();
     if (threadIdx.x != 0 || sel[slot_k] == 0) return;
-    const double r = x[3], qx = x[4], qy = x[5], qz = x[6];
-    const double q2 = r * r + qx * qx + qy * qy + qz * qz;
+    double* x = x_out;
+    const double qr = x[3], qx = x[4], qy = x[5], qz = x[6];
+    const double q2 = qr * qr + qx * qx + qy * qy + qz * qz;
     const double nrm = sqrt(q2);
-    x[3] = r / nrm; x[4] = qx / nrm; x[5] = qy / nrm; x[6] = qz / nrm;
+    x[3] = qr / nrm; x[4] = qx / nrm; x[5] = qy / nrm; x[6] = qz / nrm;
     const double scale = compat ? (1.0 / q2) : (1.0 / (q2 * nrm));
     const double rows[16] = {
-        qx*qx+qy*qy+qz*qz, -r*qx,            -r*qy,            -r*qz,
-        -qx*r,             r*r+qy*qy+qz*qz,  -qx*qy,           -qx*qz,
-        -qy*r,             -qy*qx,           r*r+qx*qx+qz*qz,  -qy*qz,
-        -qz*r,             -qz*qx,           -qz*qy,           r*r+qx*qx+qy*qy };
+        qx*qx+qy*qy+qz*qz, -qr*qx,           -qr*qy,           -qr*qz,
+        -qx*qr,            qr*qr+qy*qy+qz*qz, -qx*qy,          -qx*qz,
+        -qy*qr,            -qy*qx,           qr*qr+qx*qx+qz*qz, -qy*qz,
+        -qz*qr,            -qz*qx,           -qz*qy,           qr*qr+qx*qx+qy*qy };
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T[i + 4 * j] = scale * rows[4 * i + j];
 }
 
 void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
                          const double* A, const double* x_in, double* x_out, double* T, int compat)
 {
-    xupdate_kernel<<<dim3(d.NP / 16), dim3(256), 0, s>>>(d, sel, slot_nblk, A, x_in, x_out);
-    quat_kernel<<<dim3(1), dim3(64), 0, s>>>(sel, slot_k, x_out, T, compat);
+    xupdate_kernel<<<dim3(d.NP / 16), dim3(256), 0, s>>>(d, sel, slot_nblk, slot_k, A, x_in, x_out, T, compat);
 }
 
 // ---------------------------------------------------------------------------
@@ -1164,7 +1163,7 @@ void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel,
 __global__ void __launch_bounds__(256)
 rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
                    const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                   const int32_t* __restrict__ tile_order)
+                   const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int bi, bj;
@@ -1220,6 +1219,58 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         Cs[c * TS_LD + row] = o;
     }
     __syncthreads();
+    // K11 rides along: the Jnorm congruence on rows/columns 3..6 (ExtendKF.cpp:629-634) only touches the first
+    // block row/column, i.e. the pairs with bj == 0; same arithmetic as a separate pass over P would do
+    if (Tq && bj == 0 && sel[slot_k] != 0) {
+        double T[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T[k] = Tq[k];
+        const int j = threadIdx.x;                  // row of tile (bi,0) = column of its mirror
+        if (bi != 0) {
+            if (j < 64) {
+                double rb[4];
+                for (int i = 0; i < 4; ++i) {
+                    double sacc = 0;
+                    for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + k) * TS_LD + j];   // P(3+k, col) by symmetry
+                    rb[i] = sacc;
+                }
+                for (int i = 0; i < 4; ++i) { Cs[(3 + i) * TS_LD + j] = rb[i]; Cij[j + (long)(3 + i) * ldo] = rb[i]; }
+            }
+        } else {
+            if (j < 64 && !(j >= 3 && j < 7)) {
+                double rb[4];
+                for (int i = 0; i < 4; ++i) {
+                    double sacc = 0;
+                    for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[j * TS_LD + (3 + k)];
+                    rb[i] = sacc;
+                }
+                for (int i = 0; i < 4; ++i) { Cs[j * TS_LD + (3 + i)] = rb[i]; Cs[(3 + i) * TS_LD + j] = rb[i]; }
+            } else if (j == 3) {
+                double cb[4][4], out[4][4];         // cb = J * P44 ; out = cb * J^T
+                for (int i = 0; i < 4; ++i)
+                    for (int c = 0; c < 4; ++c) {
+                        double sacc = 0;
+                        for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + c) * TS_LD + (3 + k)];
+                        cb[i][c] = sacc;
+                    }
+                for (int i = 0; i < 4; ++i)
+                    for (int c = 0; c < 4; ++c) {
+                        double sacc = 0;
+                        for (int k = 0; k < 4; ++k) sacc += cb[i][k] * T[c + 4 * k];
+                        out[i][c] = sacc;
+                    }
+                for (int i = 0; i < 4; ++i)
+                    for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = out[i][c];
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int c = g + 4 * q;
+                Cij[row + (long)c * ldo] = Cs[c * TS_LD + row];
+            }
+        }
+        __syncthreads();
+    }
     if (bi != bj) {
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
@@ -1249,59 +1300,13 @@ void make_rank_update_order(int nT, std::vector<int32_t>& order)
 
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                        const int32_t* tile_order)
+                        const int32_t* tile_order, const double* Tq, int slot_k)
 {
     const int nT = NP / 64;
     const int tiles = nT * (nT + 1) / 2;
     if (tiles <= 0) return;
     rank_update_kernel<<<dim3(tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
-                                                                                  fixed_k, Pout, ldo, tile_order);
-}
-
-// ---------------------------------------------------------------------------
-// K11: Jnorm congruence on rows/columns 3..6 (ExtendKF.cpp:629-634).
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-quat_cov_kernel(int n, int NP, const int32_t* __restrict__ sel, int slot_k, const double* __restrict__ T,
-                double* __restrict__ P)
-{
-    if (sel[slot_k] == 0) return;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    if (j >= 3 && j < 7) {
-        if (j != 3) return;
-        double cb[4][4], out[4][4];                 // cb = J * P44 ; out = cb * J^T
-        for (int i = 0; i < 4; ++i)
-            for (int c = 0; c < 4; ++c) {
-                double sacc = 0;
-                for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * P[(3 + k) + (long)(3 + c) * NP];
-                cb[i][c] = sacc;
-            }
-        for (int i = 0; i < 4; ++i)
-            for (int c = 0; c < 4; ++c) {
-                double sacc = 0;
-                for (int k = 0; k < 4; ++k) sacc += cb[i][k] * T[c + 4 * k];
-                out[i][c] = sacc;
-            }
-        for (int i = 0; i < 4; ++i)
-            for (int c = 0; c < 4; ++c) P[(3 + i) + (long)(3 + c) * NP] = out[i][c];
-        return;
-    }
-    double rb[4];
-    for (int i = 0; i < 4; ++i) {
-        double sacc = 0;
-        for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * P[(3 + k) + (long)j * NP];
-        rb[i] = sacc;
-    }
-    for (int i = 0; i < 4; ++i) {
-        P[(3 + i) + (long)j * NP] = rb[i];
-        P[j + (long)(3 + i) * NP] = rb[i];
-    }
-}
-
-void launch_quat_cov(hipStream_t s, int n, int NP, const int32_t* sel, int slot_k, const double* T, double* P)
-{
-    quat_cov_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(n, NP, sel, slot_k, T, P);
+                                                                                  fixed_k, Pout, ldo, tile_order, Tq, slot_k);
 }
 
 // ---------------------------------------------------------------------------

@@ -100,6 +100,7 @@ struct rslam_ctx {
     // previous frame's inlier counts (+1 block of slack); the device flags an overflow
     // (STATUS_SWEEP_CAP) and the update stage is then re-run with the full-length sequence.
     int cap_li = 1 << 20, cap_hi = 1 << 20;
+    int calm_li = 0, calm_hi = 0;
     const int32_t* last_sup = nullptr;
     int reruns = 0;
 };
@@ -452,9 +453,8 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     }
     if (ev_r0 >= 0) mark(c, ev_r0);
     launch_rank_update(s, c->NP, Pin, c->NP, c->d_A.p + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
-                       (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr);
+                       (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr, c->RP > 0 ? c->d_T.p : nullptr, slot_k);
     if (ev_r1 >= 0) mark(c, ev_r1);
-    if (c->RP > 0) launch_quat_cov(s, c->n, c->NP, sel, slot_k, c->d_T.p, Pout);
     return RSLAM_OK;
 }
 
@@ -529,13 +529,18 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         if (rc) return rc;
     }
     if (c->have_meas && c->last_sup && sel[SEL_STATUS] == 0) {
-        auto adapt = [&](int& cap, int nblk) {
+        // grow at once (an overflow costs a re-run of the update stage); shrink at once when two or more block
+        // steps are wasted, and by the last one only after the count has stayed lower for 8 frames (each change
+        // of the launch sequence re-captures the hipGraphs; every empty step is two ~4.5 us launches)
+        auto adapt = [&](int& cap, int& calm, int nblk) {
             const int want = nblk + 1 < rp_blocks ? nblk + 1 : rp_blocks;
             const int cur = cap < rp_blocks ? cap : rp_blocks;
-            if (want > cur || cur - want >= 2) { cap = want; invalidate_graph(c); }
+            if (want > cur) { cap = want; calm = 0; invalidate_graph(c); }
+            else if (want < cur) { if (cur - want >= 2 || ++calm >= 8) { cap = want; calm = 0; invalidate_graph(c); } }
+            else calm = 0;
         };
-        adapt(c->cap_li, sel[SEL_NBLK_LI]);
-        adapt(c->cap_hi, sel[SEL_NBLK_HI]);
+        adapt(c->cap_li, c->calm_li, sel[SEL_NBLK_LI]);
+        adapt(c->cap_hi, c->calm_hi, sel[SEL_NBLK_HI]);
     }
     if (sel_host) memcpy(sel_host, sel, sizeof(sel));
     return sel[SEL_STATUS];
@@ -1141,7 +1146,7 @@ extern "C" int rslam_k_rank_update(rslam_ctx* c, int32_t n, int32_t r, const dou
     const int NP = round_up(n, 64), K = round_up(r, TG_KC_HOST);
     if (lda < NP || ldc < NP || ldy < NP) return RSLAM_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc, tile_order(c, NP));
+    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc, tile_order(c, NP), nullptr, 0);
     HIPCHK(hipGetLastError());
     return RSLAM_OK;
 }
