@@ -67,8 +67,10 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
                            const uint8_t* type, const double* z, const double* h, double* A,
                            const double* Wsrc, const int32_t* rank_of);
-void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
-                         int slot_k, int slot_nblk, int cap_blocks, double* A, double* Linv, int32_t* status_sel);
+// returns the buffer (A or Ystore, same shape) whose rows [RP, RP + NP] hold Y and u^T afterwards
+double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
+                            int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
+                            int32_t* status_sel);
 void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
                          const double* A, const double* x_in, double* x_out, double* T, int compat);
 // C = sym(Pin) - Y Y^T on the lower-triangle tile pairs (K from sel[slot_nblk]*64);

@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "tile_gemm.h"
 #include <vector>
+#include <cstddef>
 
 namespace rslam {
 
@@ -569,10 +570,11 @@ __device__ __forceinline__ double rsqrt_f64(double d)
 // and written once at the end (a global store inside the loop would put a vmcnt(0) wait on
 // the chain).
 constexpr int CD_LD = 65;
-constexpr int CD_TW = 5;            // T waves
-constexpr int CD_MW = 3;            // M waves
+constexpr int CD_TW = 4;            // T waves
+constexpr int CD_MW = 2;            // M waves
 constexpr int CD_THREADS = 64 * (2 + CD_TW + CD_MW);
 constexpr int CD_SPIN_LIMIT = 1 << 20;
+constexpr int CD_OPLD = 72;         // leading dimension of the operands staged for the in-kernel panel row
 
 struct CdShared {
     double Lf[64 * CD_LD];       // L, column-major
@@ -744,28 +746,22 @@ __device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
     }
 }
 
-// T wave B: tiles B and B + 5 of the trailing matrix.
+// T wave B: tiles B, B + CD_TW, ... (< 10) of the trailing matrix.
+constexpr int CD_TT = (10 + CD_TW - 1) / CD_TW;     // most tiles a T wave owns
 template <int B>
-__device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const double* tile, long ldA, int pending)
+__device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const d4 (&acc_in)[CD_TT], int pending)
 {
     const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
-    constexpr int I[2] = {B, B + CD_TW};
-    constexpr int TR0 = cd_tr(I[0]), TC0 = cd_tc(I[0]), TR1 = cd_tr(I[1]), TC1 = cd_tc(I[1]);
-    d4 acc[2];
+    constexpr int NT = (10 - B + CD_TW - 1) / CD_TW;
+    d4 acc[NT];                                       // loaded by the caller
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = 16 * cd_tr(I[o]) + lr + 4 * reg, col = 16 * cd_tc(I[o]) + lc;
-            // the lower triangle of the global tile is authoritative; mirror it
-            acc[o][reg] = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
-        }
+    for (int o = 0; o < NT; ++o) acc[o] = acc_in[o];
     if (pending) {
         __syncthreads();                 // (A) the previous panel row is staged in Lf
         const double* Xg = sh.Lf;
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int tr = cd_tr(I[o]), tc = cd_tc(I[o]);
+        for (int o = 0; o < NT; ++o) {
+            const int tr = cd_tr(B + CD_TW * o), tc = cd_tc(B + CD_TW * o);
 #pragma unroll 4
             for (int kk = 0; kk < 64; kk += 4)
                 acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xg[(kk + lr) * CD_LD + 16 * tr + lc],
@@ -775,10 +771,10 @@ __device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const double
     }
     // strip of pivot block 0
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        if (cd_tc(I[o]) == 0 && lc < 4) {
+    for (int o = 0; o < NT; ++o) {
+        if (cd_tc(B + CD_TW * o) == 0 && lc < 4) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) sh.Tst[0][lc * 64 + 16 * cd_tr(I[o]) + lr + 4 * reg] = acc[o][reg];
+            for (int reg = 0; reg < 4; ++reg) sh.Tst[0][lc * 64 + 16 * cd_tr(B + CD_TW * o) + lr + 4 * reg] = acc[o][reg];
         }
     }
     __syncthreads();                     // (C) strips, cleared collectors and flags are visible
@@ -794,23 +790,26 @@ __device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const double
                 cd_wait<1>(sh, s, 0, 0, 0);                  // panel s-1 (which also means the panel wave is done with strip buffer (s+1) & 1)
                 CD_STAMP(s1);
                 const double* Xp = sh.Xs[(q + 3) & 3];
-                const double a0 = Xp[lr * 64 + 16 * TR0 + lc], b0 = Xp[lr * 64 + 16 * TC0 + lc];
-                const double a1 = Xp[lr * 64 + 16 * TR1 + lc], b1 = Xp[lr * 64 + 16 * TC1 + lc];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, -b0, acc[0], 0, 0, 0);   // T -= X X^T
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, -b1, acc[1], 0, 0, 0);
+                double a[NT], b[NT];
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    a[o] = Xp[lr * 64 + 16 * cd_tr(B + CD_TW * o) + lc];
+                    b[o] = Xp[lr * 64 + 16 * cd_tc(B + CD_TW * o) + lc];
+                }
+#pragma unroll
+                for (int o = 0; o < NT; ++o) acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);   // T -= X X^T
                 CD_ACC_T(3, s0, s1, 128);
             }
             // strip of block s+1 (updates <= s-1 applied)
             if (p0 + 4 < 64) {
                 const int p1 = p0 + 4, bb = p1 >> 4, o1 = p1 & 15;
                 double* To = sh.Tst[(q + 1) & 1];
-                if (TC0 == bb && lc >= o1 && lc < o1 + 4) {
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) To[(lc - o1) * 64 + 16 * TR0 + lr + 4 * reg] = acc[0][reg];
-                }
-                if (TC1 == bb && lc >= o1 && lc < o1 + 4) {
+                for (int o = 0; o < NT; ++o) {
+                    if (cd_tc(B + CD_TW * o) == bb && lc >= o1 && lc < o1 + 4) {
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) To[(lc - o1) * 64 + 16 * TR1 + lr + 4 * reg] = acc[1][reg];
+                        for (int reg = 0; reg < 4; ++reg) To[(lc - o1) * 64 + 16 * cd_tr(B + CD_TW * o) + lr + 4 * reg] = acc[o][reg];
+                    }
                 }
             }
             cd_post(sh, 2 + B, s + 1);
@@ -820,12 +819,12 @@ __device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const double
     }
 }
 
-// M wave C: tiles C, C + 3, C + 6 (and 9 for C = 0) of the running inverse.
+// M wave C: tiles C, C + CD_MW, ... (< 10) of the running inverse.
 template <int C>
 __device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
 {
     const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
-    constexpr int NT = (C == 0) ? 4 : 3;
+    constexpr int NT = (10 - C + CD_MW - 1) / CD_MW;
     d4 acc[NT];
 #pragma unroll
     for (int o = 0; o < NT; ++o)
@@ -879,9 +878,57 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
     double* Lout = Linv + (long)step * 64 * 64;
+    // T waves: the two tiles of the block they own, read first so that the latency hides under what follows
+    d4 tacc[CD_TT];
+#pragma unroll
+    for (int o = 0; o < CD_TT; ++o) tacc[o] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (wave >= 2 && wave < 2 + CD_TW) {
+        const int l = t & 63, lr = l >> 4, lc = l & 15;
+#pragma unroll
+        for (int o = 0; o < CD_TT; ++o) {
+            const int idx = (wave - 2) + CD_TW * o;
+            if (idx >= 10) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * cd_tr(idx) + lr + 4 * reg, col = 16 * cd_tc(idx) + lc;
+                // the lower triangle of the global tile is authoritative; mirror it
+                tacc[o][reg] = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
+            }
+        }
+    }
+    if (pending == 2) {
+        // Single-launch block step: the panel row of THIS block for the previous column, X = A(k,k-1) Linv(k-1)^T,
+        // is formed here (nobody else needs it: the tile workgroups of the same launch recompute the S-row panels
+        // they use).  Operands staged behind Lf, over members that are initialised afterwards.
+        double* Aop = sh.Mf;                         // [m][CD_OPLD] : A(k,k-1)(row, m)
+        double* Lop = sh.Mf + 64 * CD_OPLD;          // [m][CD_OPLD] : Linv(k-1)(c, m)
+        const double* Ag = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
+        const double* Lg = Linv + (long)(step - 1) * 64 * 64;
+        const int row = t & 63, g = t >> 6;
+        for (int m = g; m < 64; m += CD_THREADS / 64) {
+            Aop[m * CD_OPLD + row] = Ag[row + (long)m * ldA];
+            Lop[m * CD_OPLD + row] = Lg[row + 64 * m];
+        }
+        __syncthreads();
+        if (wave < 8) {
+            const int l = t & 63, lr = l >> 4, lc = l & 15;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int tr = (2 * wave + o) >> 2, tc = (2 * wave + o) & 3;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int kk = 0; kk < 64; kk += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[(kk + lr) * CD_OPLD + 16 * tr + lc],
+                                                               Lop[(kk + lr) * CD_OPLD + 16 * tc + lc], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) sh.Lf[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
+            }
+        }
+        __syncthreads();
+    }
     {
         const int row = t & 63, g = t >> 6;
-        if (pending) {
+        if (pending == 1) {
             // Lookahead: the trailing update of step-1 for THIS tile, A(k,k) -= X X^T with X = A(k,k-1)
             // (already solved by panel(step-1)), is applied by the T waves so that the trailing-update
             // kernel of the previous step can run elsewhere while this block is factored.
@@ -904,14 +951,12 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         else cd_inverse_wave(sh, n_piv4);
     } else {
         switch (wave) {
-        case 2: cd_t_wave<0>(sh, n_piv4, tile, ldA, pending); break;
-        case 3: cd_t_wave<1>(sh, n_piv4, tile, ldA, pending); break;
-        case 4: cd_t_wave<2>(sh, n_piv4, tile, ldA, pending); break;
-        case 5: cd_t_wave<3>(sh, n_piv4, tile, ldA, pending); break;
-        case 6: cd_t_wave<4>(sh, n_piv4, tile, ldA, pending); break;
-        case 7: cd_m_wave<0>(sh, n_piv4, pending); break;
-        case 8: cd_m_wave<1>(sh, n_piv4, pending); break;
-        default: cd_m_wave<2>(sh, n_piv4, pending); break;
+        case 2: cd_t_wave<0>(sh, n_piv4, tacc, pending); break;
+        case 3: cd_t_wave<1>(sh, n_piv4, tacc, pending); break;
+        case 4: cd_t_wave<2>(sh, n_piv4, tacc, pending); break;
+        case 5: cd_t_wave<3>(sh, n_piv4, tacc, pending); break;
+        case 6: cd_m_wave<0>(sh, n_piv4, pending); break;
+        default: cd_m_wave<1>(sh, n_piv4, pending); break;
         }
     }
     __syncthreads();
@@ -1011,29 +1056,99 @@ trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     trail_tile(A, ldA, step, sel[slot_nblk], rp_blocks, blockIdx.x, blockIdx.y + step + 1, skip_next_diag, lds);
 }
 
-// Trailing update of step k and the factorisation of diagonal block k+1 in ONE launch: workgroup 0
-// applies the step-k update to tile (k+1,k+1) itself (cd_factor_block, pending) and factors it while
-// the other workgroups update the remaining tiles, so the serial chain per block step is
-// panel + max(trailing, diagonal) instead of their sum.  All workgroups have the diagonal block's
-// shape (CD_THREADS); the tile workgroups retire their surplus waves at once.
+// One launch per block step k of the sweep:
+//   workgroup 0      forms its own panel row X = A(k+1,k) Linv(k)^T, applies the step-k update to tile
+//                    (k+1,k+1) and factors it (cd_factor_block, pending = 2): the serial chain of the sweep;
+//   workgroup (i,j)  tile (i,j), j = k+1+jj: recomputes the two panel blocks it needs,
+//                    Y_i = A(i,k) Linv(k)^T and Y_j = A(j,k) Linv(k)^T, as LDS-resident MFMA operands and
+//                    applies A(i,j) -= Y_i Y_j^T; the jj = 0 column also stores Y_i for the P H^T / nu rows into
+//                    a second buffer of the same shape (the S-row panels are never read again, so they are
+//                    never written; A(i,k) itself is read by the other tiles of row i during the launch).
+// The panel solve thus leaves the chain: a block step costs max(diagonal path, three K = 64 tile products)
+// instead of panel launch + max(trailing, diagonal).  All workgroups have the diagonal block's shape
+// (CD_THREADS); the tile workgroups retire their surplus waves at once.
+__device__ __forceinline__ void step_tile(double* __restrict__ A, long ldA, int step, int nblk, int rp_blocks,
+                                          int i, int j, const double* __restrict__ Linv_k, double* __restrict__ Yout, double* lds)
+{
+    if (!row_block_active(i, step, nblk, rp_blocks)) return;
+    const bool has_col = (j < nblk) && (i >= j) && !(i == step + 1 && j == step + 1);   // (k+1,k+1) belongs to workgroup 0
+    const bool store_y = (j == step + 1) && (i >= rp_blocks);
+    if (!has_col && !store_y) return;
+    double* bufA = lds;                               // A(i,k), then Y_i
+    double* bufB = lds + 2 * TG_OPER_DOUBLES;         // Linv(k)
+    double* bufC = lds + 4 * TG_OPER_DOUBLES;         // A(j,k), then Y_j
+    double* Ai = A + (long)i * 64 + (long)step * 64 * ldA;
+    double* C = A + (long)i * 64 + (long)j * 64 * ldA;
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const bool two = has_col && i != j;
+    // every global read of the tile is issued before the first wait: one memory latency for the whole tile
+    tg_fill64(Ai, ldA, bufA);
+    tg_fill64(Linv_k, 64, bufB);
+    if (two) tg_fill64(A + (long)j * 64 + (long)step * 64 * ldA, ldA, bufC);
+    __syncthreads();
+    d4 yi[2][2], yj[2][2];
+    tg_zero(yi);
+    tg_gemm64_lds(bufA, bufB, yi);                    // Y_i = A(i,k) Linv^T
+    __builtin_amdgcn_sched_barrier(0);                // keep the two products' LDS prefetch windows apart (register pressure)
+    if (two) {
+        tg_zero(yj);
+        tg_gemm64_lds(bufC, bufB, yj);                // Y_j = A(j,k) Linv^T
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double cin[16];                                   // the tile to update: in flight under the last product
+    if (has_col) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cin[q] = C[row + (long)(g + 4 * q) * ldA];
+    }
+    __syncthreads();
+    // the products become operands: a 64 x 64 result written with the operand leading dimension IS two operand buffers
+    tg_acc_to_lds<TG_LD>(yi, bufA, 1.0);
+    if (two) tg_acc_to_lds<TG_LD>(yj, bufC, 1.0);
+    __syncthreads();
+    const double* Yj = two ? bufC : bufA;
+    if (store_y) {                                    // into the copy of the system: A(i,k) itself is still being read by the row's other tiles
+        double* Yi = Yout + (long)i * 64 + (long)step * 64 * ldA;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) { const int c = g + 4 * q; Yi[row + (long)c * ldA] = bufA[c * TG_LD + row]; }
+    }
+    if (!has_col) return;
+    d4 acc[2][2];
+    tg_zero(acc);
+    tg_gemm64_lds(bufA, Yj, acc);                     // Y_i Y_j^T
+    __syncthreads();
+    tg_acc_to_lds(acc, lds, 1.0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        C[row + (long)c * ldA] = cin[q] - lds[c * TS_LD + row];
+    }
+}
+
 __global__ void __launch_bounds__(CD_THREADS)
-trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-                  int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
+sweep_step_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+                  int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, double* __restrict__ Yout,
+                  int32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int nblk = sel[slot_nblk];
-    if (step + 1 >= nblk) return;                                 // no trailing matrix left
+    if (step >= nblk) return;
     if (blockIdx.x == 0) {
-        cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 1);
+        if (step + 1 < nblk)
+            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 2);
         return;
     }
     if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
     const int b = blockIdx.x - 1;
-    trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
+    step_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, Linv + (long)step * 64 * 64, Yout, lds);
 }
 
 // dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
-constexpr size_t CD_LDS_BYTES = sizeof(CdShared) > sizeof(double) * TG_LDS_DOUBLES ? sizeof(CdShared) : sizeof(double) * TG_LDS_DOUBLES;
+constexpr size_t CD_STAGE_BYTES = sizeof(double) * (64 * CD_LD + 2 * 64 * CD_OPLD);      // Lf + the two staged operands
+constexpr size_t cd_max(size_t a, size_t b) { return a > b ? a : b; }
+constexpr size_t CD_LDS_BYTES = cd_max(cd_max(sizeof(CdShared), CD_STAGE_BYTES), sizeof(double) * 6 * TG_OPER_DOUBLES);
+static_assert(CD_TW == 4 && CD_MW == 2, "the role dispatch of cd_factor_block is written out for 4 T waves and 2 M waves");
+static_assert(offsetof(CdShared, Mf) == sizeof(double) * 64 * CD_LD, "the staged operands start where Mf starts");
 
 #if defined(CD_STAMPS)
 int debug_read_cd_stamps(unsigned long long* out, int reset)
@@ -1054,19 +1169,21 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
 
-// One stream: diag(0), then per block step panel(k) and the fused trail(k) + diag(k+1).
+// One stream: diag(0), then ONE launch per block step (sweep_step_kernel).
 // RSLAM_SWEEP_UNFUSED=1 selects the three-kernels-per-step sequence (diag(k) panel(k) trail(k)) for
 // measurement.  A two-stream lookahead variant (aux != nullptr) is kept for measurement only:
 // on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the trailing kernels
 // they hide (C3 frame 0.68 ms against 0.52 ms single-stream, eager and hipGraph alike).
-void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
-                         const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Linv,
-                         int32_t* status_sel)
+// Returns the buffer whose rows [RP, RP + NP] hold Y and u^T afterwards: Ystore for the one-launch-per-step
+// sequence, A itself for the others.
+double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
+                            const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
+                            int32_t* status_sel)
 {
     const int rp_blocks = d.RP / 64;
     const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
@@ -1075,15 +1192,12 @@ void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * r
     const bool two = (aux != nullptr && ev != nullptr);
     static const bool unfused = getenv("RSLAM_SWEEP_UNFUSED") != nullptr;
     if (!two && !unfused) {
-        if (steps <= 0) return;
+        if (steps <= 0) return Ystore;
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
-        for (int step = 0; step < steps; ++step) {
-            panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
-            if (step + 1 < steps)
-                trail_diag_kernel<<<dim3(1 + row_blocks * (steps - step - 1)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
-                    A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
-        }
-        return;
+        for (int step = 0; step < steps; ++step)     // column jj = 0 also stores the panel, so the last step still has one
+            sweep_step_kernel<<<dim3(1 + row_blocks * (steps - step)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
+                A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel);
+        return Ystore;
     }
     for (int step = 0; step < steps; ++step) {
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, step, sel, slot_nblk, slot_k, Linv, status_sel, (two && step > 0) ? 1 : 0);
@@ -1101,6 +1215,7 @@ void launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * r
         }
     }
     // the last trail(steps-2) was joined before panel(steps-1): nothing is left on aux
+    return A;
 }
 
 // ---------------------------------------------------------------------------

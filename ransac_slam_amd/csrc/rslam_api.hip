@@ -72,7 +72,7 @@ struct rslam_ctx {
     DevBuf<int32_t> d_off, d_mfeat, d_moff, d_mith, d_miph, d_mzsrc, d_rank_of, d_pos, d_nhyp,
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
-    DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Linv,
+    DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Y, d_Linv,
                    d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr;
     DevBuf<uint8_t> d_image;
     // feature store: initialisation records of Map::initialize_a_features (Map.cpp:286-292), one slot per feature
@@ -173,7 +173,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_masks.release(); c->d_posmask.release();
     c->d_xpred.release(); c->d_Ppred.release(); c->d_h.release(); c->d_h2.release(); c->d_H13.release();
     c->d_H13b.release(); c->d_S.release(); c->d_S2.release(); c->d_z.release(); c->d_wv.release();
-    c->d_W.release(); c->d_A.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
+    c->d_W.release(); c->d_A.release(); c->d_Y.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release();
@@ -329,7 +329,7 @@ static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic,
     ENS(c->d_masks, (size_t)H * (words ? words : 1)); ENS(c->d_posmask, (size_t)m * (words ? words : 1));
     ENS(c->d_lilist, m); ENS(c->d_hilist, m);
     ENS(c->d_wv, 2 * (size_t)m); ENS(c->d_W, (size_t)c->NP * 2 * (m ? m : 1));
-    ENS(c->d_A, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Linv, (size_t)64 * 64 * (RP / 64 ? RP / 64 : 1));
+    ENS(c->d_A, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Y, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Linv, (size_t)64 * 64 * (RP / 64 ? RP / 64 : 1));
     if (re) invalidate_graph(c);
 #undef ENS
     hipStream_t s = c->stream;
@@ -433,6 +433,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p,
                           Wsrc, c->d_rank_of.p);
     if (ev_f0 >= 0) mark(c, ev_f0);
+    const double* Ysys = c->d_A.p;        // the system whose lower rows hold Y = P H^T L^-T and u^T after the sweep
     {
         const size_t need = 2 * (size_t)(c->RP / 64 + 1);
         while (c->sweep_ev.size() < need) {
@@ -442,17 +443,17 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         }
         static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // measured slower: off
         const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
-        launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk, cap,
-                            c->d_A.p, c->d_Linv.p, sel + SEL_STATUS);
+        Ysys = launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk,
+                                   cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS);
     }
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP > 0) {
-        launch_state_update(s, d, sel, slot_k, slot_nblk, c->d_A.p, x_in, x_out, c->d_T.p, c->cfg.compat);
+        launch_state_update(s, d, sel, slot_k, slot_nblk, Ysys, x_in, x_out, c->d_T.p, c->cfg.compat);
     } else {
         HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
     }
     if (ev_r0 >= 0) mark(c, ev_r0);
-    launch_rank_update(s, c->NP, Pin, c->NP, c->d_A.p + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
+    launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
                        (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr, c->RP > 0 ? c->d_T.p : nullptr, slot_k);
     if (ev_r1 >= 0) mark(c, ev_r1);
     return RSLAM_OK;

@@ -203,6 +203,7 @@ constexpr int TS_LD = 65;
 constexpr int TS_DOUBLES = 64 * TS_LD;
 static_assert(TG_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 tiles in the operand buffers");
 
+template <int LD = 65>
 __device__ __forceinline__ void tg_acc_to_lds(const d4 (&acc)[2][2], double* Cs, double scale)
 {
     const int lane = threadIdx.x & 63;
@@ -217,8 +218,28 @@ __device__ __forceinline__ void tg_acc_to_lds(const d4 (&acc)[2][2], double* Cs,
             for (int t = 0; t < 4; ++t) {
                 const int row = wm * 32 + mi * 16 + 4 * blk + i;
                 const int col = wn * 32 + ni * 16 + 4 * ((blk - t) & 3) + j;
-                Cs[col * TS_LD + row] = acc[mi][ni][t] * scale;
+                Cs[col * LD + row] = acc[mi][ni][t] * scale;
             }
+}
+
+// A 64 x 64 operand from global memory into two consecutive operand buffers (k = 0..31, 32..63).
+__device__ __forceinline__ void tg_fill64(const double* __restrict__ G, long ldg, double* S)
+{
+    const int t = threadIdx.x;
+    const int rp = t & 31, cq = t >> 5;
+    d2 r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const d2*>(G + 2 * rp + (long)(cq + 8 * q) * ldg);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<d2*>(S + (cq + 8 * q) * TG_LD + 2 * rp) = r[q];
+}
+
+// acc += A * B^T for two 64 x 64 operands already resident in LDS in operand layout ([k][TG_LD], i.e. a
+// 64 x 64 matrix stored column-major with leading dimension TG_LD spans two consecutive operand buffers)
+__device__ __forceinline__ void tg_gemm64_lds(const double* As, const double* Bs, d4 (&acc)[2][2])
+{
+    tg_compute_chunk(As, Bs, acc);
+    tg_compute_chunk(As + TG_OPER_DOUBLES, Bs + TG_OPER_DOUBLES, acc);
 }
 
 }  // namespace rslam
