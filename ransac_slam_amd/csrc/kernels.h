@@ -11,7 +11,7 @@ namespace rslam {
 // d_sel[] slots (device-side frame scalars)
 enum SelSlot {
     SEL_BEST_HYP = 0, SEL_BEST_SUPPORT = 1, SEL_HYPS_EVALUATED = 2,
-    SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7,
+    SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7, SEL_XU_FLAG = 8,
     SEL_COUNT = 16
 };
 // internal device status: the captured launch sequence of a factor sweep was shorter than the
@@ -71,15 +71,22 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
 double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
                             int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
                             int32_t* status_sel);
-void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
-                         const double* A, const double* x_in, double* x_out, double* T, int compat);
+// K9 riding in the rank-update launch: the first `groups` workgroups compute x_k_k = x + Y u (16 rows each),
+// group 0 the quaternion normalisation and Jnorm, published through *flag = token (sel[SEL_XU_FLAG])
+struct XuArgs {
+    int groups;                 // 0 = no x update in this launch
+    SystemDims d;
+    const double* A;            // the system whose rows [RP, RP + NP] hold Y and u^T
+    const double* x_in; double* x_out; double* T;
+    int compat; int token; int32_t* flag;
+};
 // C = sym(Pin) - Y Y^T on the lower-triangle tile pairs (K from sel[slot_nblk]*64);
 // K == 0: C = Pin exactly (ExtendKF.cpp:635-638 pass-through)
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
                         const int32_t* tile_order /* nullable: row-major triangle */,
                         const double* Tq /* nullable: 4 x 4 Jnorm, applied to rows/columns 3..6 (K11) when sel[slot_k] != 0 */,
-                        int slot_k);
+                        int slot_k, const XuArgs* xu /* nullable */);
 void make_rank_update_order(int nT, std::vector<int32_t>& order);   // XCD-aware (bi << 16 | bj) per block
 
 // x_pred[0:13], FQ (338 doubles) and the 13-row/column strips of P_pred; the caller copies

@@ -651,6 +651,9 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
     const int l = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);                          // the chain wins every issue arbitration on its SIMD
     double xp0 = 0.0, xp1 = 0.0, xp2 = 0.0, xp3 = 0.0;     // own row of the previous panel
+    // flag li must reach s + need_off: T waves s, inverse wave and M waves s - 1, nothing else
+    const int need_off = ((threadIdx.x & 15) >= 2 && (threadIdx.x & 15) < 2 + CD_TW) ? 0
+                       : ((threadIdx.x & 15) == 1 || ((threadIdx.x & 15) >= 2 + CD_TW && (threadIdx.x & 15) < 2 + CD_TW + CD_MW)) ? -1 : -(1 << 30);
 #pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
@@ -659,18 +662,38 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
             const int p0 = 16 * sb + 4 * q;
             if (s >= n_piv4) return;                      // uniform: only identity padding is left
             CD_STAMP(s0);
-            // strip of block s (T waves, iteration s-1); panel buffer s & 3 free: inverse wave past block
-            // s-3, M waves past iteration s-2; Rs buffer free: inverse wave past block s-2
-            cd_wait<0>(sh, 0, s - 1, s, s - 1);
-            CD_STAMP(s1);
+            // Needs: strip of block s (T waves, iteration s-1); panel buffer s & 3 free: inverse wave past block
+            // s-3, M waves past iteration s-2; Rs buffer free: inverse wave past block s-2.
+            // The flags and the data are read in ONE batch: LDS serves a wave's requests in order, so data read
+            // after a flag that says "ready" is the published data; only if a flag was not ready yet (it almost
+            // never is not: the other waves have a whole iteration of slack) everything is read again.
             const double* Tc = sh.Tst[q & 1];
             const double* Xp = sh.Xs[(q + 3) & 3];        // panel s-1 (zeros for s = 0)
-            double a0 = Tc[l], a1 = Tc[64 + l], a2 = Tc[128 + l], a3 = Tc[192 + l];
+            double a0, a1, a2, a3, u[16];
+            {
+                const int li = threadIdx.x & 15;
+                const int need = s + need_off;
+                int spins = 0;
+                while (true) {
+                    const int v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);             // compiler: keep the data reads behind the flag read
+                    a0 = Tc[l]; a1 = Tc[64 + l]; a2 = Tc[128 + l]; a3 = Tc[192 + l];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) u[4 * j + k] = Xp[j * 64 + p0 + k];
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    if (__all(v >= need)) break;
+                    if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                }
+            }
+            CD_STAMP(s1);
+            __builtin_amdgcn_sched_barrier(0);
             // strip row l: T(l, p0+k) -= sum_j X_prev(l, j) X_prev(p0+k, j)
-            a0 = fma(-xp0, Xp[p0 + 0], a0); a1 = fma(-xp0, Xp[p0 + 1], a1); a2 = fma(-xp0, Xp[p0 + 2], a2); a3 = fma(-xp0, Xp[p0 + 3], a3);
-            a0 = fma(-xp1, Xp[64 + p0 + 0], a0); a1 = fma(-xp1, Xp[64 + p0 + 1], a1); a2 = fma(-xp1, Xp[64 + p0 + 2], a2); a3 = fma(-xp1, Xp[64 + p0 + 3], a3);
-            a0 = fma(-xp2, Xp[128 + p0 + 0], a0); a1 = fma(-xp2, Xp[128 + p0 + 1], a1); a2 = fma(-xp2, Xp[128 + p0 + 2], a2); a3 = fma(-xp2, Xp[128 + p0 + 3], a3);
-            a0 = fma(-xp3, Xp[192 + p0 + 0], a0); a1 = fma(-xp3, Xp[192 + p0 + 1], a1); a2 = fma(-xp3, Xp[192 + p0 + 2], a2); a3 = fma(-xp3, Xp[192 + p0 + 3], a3);
+            a0 = fma(-xp0, u[0], a0); a1 = fma(-xp0, u[1], a1); a2 = fma(-xp0, u[2], a2); a3 = fma(-xp0, u[3], a3);
+            a0 = fma(-xp1, u[4], a0); a1 = fma(-xp1, u[5], a1); a2 = fma(-xp1, u[6], a2); a3 = fma(-xp1, u[7], a3);
+            a0 = fma(-xp2, u[8], a0); a1 = fma(-xp2, u[9], a1); a2 = fma(-xp2, u[10], a2); a3 = fma(-xp2, u[11], a3);
+            a0 = fma(-xp3, u[12], a0); a1 = fma(-xp3, u[13], a1); a2 = fma(-xp3, u[14], a2); a3 = fma(-xp3, u[15], a3);
             CD_PIN4(a0, a1, a2, a3);
             CD_STAMP(sa);
             // right-looking Cholesky over the 4 columns, lane = row
@@ -721,21 +744,28 @@ __device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
             const double* Xc = sh.Xs[q];                  // panel s: rows p0..p0+3 are L4
             const double* R = sh.Rs[q & 1];
             double a0 = Mc[l], a1 = Mc[64 + l], a2 = Mc[128 + l], a3 = Mc[192 + l];
+            double u[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[4 * j + k] = Xp[j * 64 + p0 + k];
+            const double l10 = Xc[p0 + 1], l20 = Xc[p0 + 2], l30 = Xc[p0 + 3];
+            const double l21 = Xc[64 + p0 + 2], l31 = Xc[64 + p0 + 3], l32 = Xc[128 + p0 + 3];
+            const double q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
+            __builtin_amdgcn_sched_barrier(0);           // every LDS read of the block is in flight before the arithmetic starts
             {   // strip column l: M(p0+k, l) -= sum_j X_prev(p0+k, j) Ms_prev(j, l)
                 const double ms[4] = {mp0, mp1, mp2, mp3};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a0 = fma(-Xp[j * 64 + p0 + 0], ms[j], a0); a1 = fma(-Xp[j * 64 + p0 + 1], ms[j], a1);
-                    a2 = fma(-Xp[j * 64 + p0 + 2], ms[j], a2); a3 = fma(-Xp[j * 64 + p0 + 3], ms[j], a3);
+                    a0 = fma(-u[4 * j + 0], ms[j], a0); a1 = fma(-u[4 * j + 1], ms[j], a1);
+                    a2 = fma(-u[4 * j + 2], ms[j], a2); a3 = fma(-u[4 * j + 3], ms[j], a3);
                 }
             }
-            const double l10 = Xc[p0 + 1], l20 = Xc[p0 + 2], l30 = Xc[p0 + 3];
-            const double l21 = Xc[64 + p0 + 2], l31 = Xc[64 + p0 + 3], l32 = Xc[128 + p0 + 3];
             // entries right of the pivot columns come out as exact zeros (M is lower triangular)
-            mp0 = a0 * R[0];
-            mp1 = fma(-l10, mp0, a1) * R[1];
-            mp2 = fma(-l21, mp1, fma(-l20, mp0, a2)) * R[2];
-            mp3 = fma(-l32, mp2, fma(-l31, mp1, fma(-l30, mp0, a3))) * R[3];
+            mp0 = a0 * q0;
+            mp1 = fma(-l10, mp0, a1) * q1;
+            mp2 = fma(-l21, mp1, fma(-l20, mp0, a2)) * q2;
+            mp3 = fma(-l32, mp2, fma(-l31, mp1, fma(-l30, mp0, a3))) * q3;
             double* Mo = sh.Ms[q & 1];
             Mo[l] = mp0; Mo[64 + l] = mp1; Mo[128 + l] = mp2; Mo[192 + l] = mp3;
             // column l of rows p0..p0+3 of L^-1 (final)
@@ -1223,15 +1253,17 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
 // normalisation and the Jnorm matrix (:613-627; Q6: exponent -3/2 is integer
 // division => 1/|q|^2 in compat mode).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, int slot_k, const double* __restrict__ A,
-               const double* __restrict__ x_in, double* __restrict__ x_out, double* __restrict__ T, int compat)
+// x_k_k rows of one 16-row group; group 0 also normalises the quaternion, writes Jnorm (T) and, when
+// `flag` is given, publishes flag = token for the workgroups of the same launch that apply Jnorm
+__device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, int slot_k,
+                                             const double* __restrict__ A, const double* __restrict__ x_in,
+                                             double* __restrict__ x_out, double* __restrict__ T, int compat,
+                                             int32_t* flag, int token, double (*part)[17])
 {
     // 16 rows x 16 K-slices per workgroup; fixed-order LDS reduction (bitwise reproducible)
-    __shared__ double part[16][17];
     const int K = 64 * sel[slot_nblk];
     const int r = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int row = blockIdx.x * 16 + r;
+    const int row = group * 16 + r;
     const double* Y = A + d.RP;
     const double* u = A + d.RP + d.NP;
     double acc = 0;
@@ -1244,11 +1276,15 @@ xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, int
         for (int q = 0; q < 16; ++q) ssum += part[q][r];
         x_out[row] = x_in[row] + ssum;
     }
-    // the quaternion lives in rows 3..6 of workgroup 0: normalisation and Jnorm ride along
-    if (blockIdx.x != 0) return;
+    // the quaternion lives in rows 3..6 of group 0: normalisation and Jnorm ride along
+    if (group != 0) return;
     __threadfence_block();
     __syncthreads();
-    if (threadIdx.x != 0 || sel[slot_k] == 0) return;
+    if (threadIdx.x != 0) return;
+    if (sel[slot_k] == 0) {
+        if (flag) { __threadfence(); __hip_atomic_store(flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+    }
     double* x = x_out;
     const double qr = x[3], qx = x[4], qy = x[5], qz = x[6];
     const double q2 = qr * qr + qx * qx + qy * qy + qz * qz;
@@ -1261,12 +1297,7 @@ xupdate_kernel(SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, int
         -qy*qr,            -qy*qx,           qr*qr+qx*qx+qz*qz, -qy*qz,
         -qz*qr,            -qz*qx,           -qz*qy,           qr*qr+qx*qx+qy*qy };
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T[i + 4 * j] = scale * rows[4 * i + j];
-}
-
-void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk,
-                         const double* A, const double* x_in, double* x_out, double* T, int compat)
-{
-    xupdate_kernel<<<dim3(d.NP / 16), dim3(256), 0, s>>>(d, sel, slot_nblk, slot_k, A, x_in, x_out, T, compat);
+    if (flag) { __threadfence(); __hip_atomic_store(flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // ---------------------------------------------------------------------------
@@ -1278,18 +1309,27 @@ void launch_state_update(hipStream_t s, const SystemDims& d, const int32_t* sel,
 __global__ void __launch_bounds__(256)
 rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
                    const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                   const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k)
+                   const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k, XuArgs xu)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // The first xu.groups workgroups are K9 riding along: x_k_k = x + Y u needs the same finished sweep as this
+    // kernel and nothing of its output, so it does not deserve a launch of its own.  Group 0 also produces Jnorm,
+    // which the bj == 0 tiles below wait for (they are dispatched after it and need it ~50 us later).
+    if ((int)blockIdx.x < xu.groups) {
+        xupdate_rows(blockIdx.x, xu.d, sel, slot_nblk, slot_k, xu.A, xu.x_in, xu.x_out, xu.T, xu.compat, xu.flag, xu.token,
+                     reinterpret_cast<double (*)[17]>(lds));
+        return;
+    }
+    const int tile_index = blockIdx.x - xu.groups;
     int bi, bj;
     if (tile_order) {
         // XCD-aware order (make_rank_update_order): the tiles one XCD's L2 sees form 8 x 8 regions of
         // the triangle, so it fetches ~16 of the Y row panels instead of all of them
-        const int e = tile_order[blockIdx.x];
+        const int e = tile_order[tile_index];
         bi = e >> 16; bj = e & 0xffff;
     } else {
         // linear index -> (bi >= bj), row-major over the lower triangle
-        const int t = blockIdx.x;
+        const int t = tile_index;
         bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((long)bi * (bi + 1) / 2 > t) --bi;
         while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -1337,6 +1377,13 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     // K11 rides along: the Jnorm congruence on rows/columns 3..6 (ExtendKF.cpp:629-634) only touches the first
     // block row/column, i.e. the pairs with bj == 0; same arithmetic as a separate pass over P would do
     if (Tq && bj == 0 && sel[slot_k] != 0) {
+        if (xu.groups > 0) {                        // Jnorm comes from group 0 of this launch
+            int spins = 0;
+            while (__hip_atomic_load(xu.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < xu.token) {
+                if (++spins > (1 << 22)) { atomicMin(const_cast<int32_t*>(sel) + SEL_STATUS, -3); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         double T[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) T[k] = Tq[k];
@@ -1415,13 +1462,15 @@ void make_rank_update_order(int nT, std::vector<int32_t>& order)
 
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                        const int32_t* tile_order, const double* Tq, int slot_k)
+                        const int32_t* tile_order, const double* Tq, int slot_k, const XuArgs* xu)
 {
     const int nT = NP / 64;
     const int tiles = nT * (nT + 1) / 2;
     if (tiles <= 0) return;
-    rank_update_kernel<<<dim3(tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
-                                                                                  fixed_k, Pout, ldo, tile_order, Tq, slot_k);
+    XuArgs none{}; none.groups = 0;
+    const XuArgs& x = xu ? *xu : none;
+    rank_update_kernel<<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
+                                                                                             fixed_k, Pout, ldo, tile_order, Tq, slot_k, x);
 }
 
 // ---------------------------------------------------------------------------

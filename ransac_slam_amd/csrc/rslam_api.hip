@@ -447,14 +447,16 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
                                    cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS);
     }
     if (ev_f1 >= 0) mark(c, ev_f1);
-    if (c->RP > 0) {
-        launch_state_update(s, d, sel, slot_k, slot_nblk, Ysys, x_in, x_out, c->d_T.p, c->cfg.compat);
-    } else {
-        HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
-    }
+    if (c->RP <= 0) HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
     if (ev_r0 >= 0) mark(c, ev_r0);
+    // K9 (x_k_k = x + Y u, quaternion normalisation, Jnorm) rides in the rank-update launch
+    XuArgs xu{};
+    xu.groups = c->RP > 0 ? c->NP / 16 : 0;
+    xu.d = d; xu.A = Ysys; xu.x_in = x_in; xu.x_out = x_out; xu.T = c->d_T.p; xu.compat = c->cfg.compat;
+    xu.token = (slot_k == SEL_K_LI) ? 1 : 2;              // sel[] is zeroed at the start of a frame (predict_kernel)
+    xu.flag = sel + SEL_XU_FLAG;
     launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
-                       (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr, c->RP > 0 ? c->d_T.p : nullptr, slot_k);
+                       (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr, c->RP > 0 ? c->d_T.p : nullptr, slot_k, &xu);
     if (ev_r1 >= 0) mark(c, ev_r1);
     return RSLAM_OK;
 }
@@ -523,6 +525,7 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         ++c->reruns;
         const int timing = c->timing; c->timing = 0;
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));     // Jnorm hand-over of the rank-update launches
         rc = enqueue_update(c, c->last_sup);
         c->timing = timing;
         if (rc) return rc;
@@ -533,15 +536,19 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         // grow at once (an overflow costs a re-run of the update stage); shrink at once when two or more block
         // steps are wasted, and by the last one only after the count has stayed lower for 8 frames (each change
         // of the launch sequence re-captures the hipGraphs; every empty step is two ~4.5 us launches)
-        auto adapt = [&](int& cap, int& calm, int nblk) {
-            const int want = nblk + 1 < rp_blocks ? nblk + 1 : rp_blocks;
+        // room for 8 more inlier features than this frame had (16 rows), not a whole spare block: every block
+        // step that turns out empty is a ~4.5 us launch
+        auto adapt = [&](int& cap, int& calm, int k) {
+            int want = (2 * k + 16 + 63) / 64;
+            if (want < 1) want = 1;
+            if (want > rp_blocks) want = rp_blocks;
             const int cur = cap < rp_blocks ? cap : rp_blocks;
             if (want > cur) { cap = want; calm = 0; invalidate_graph(c); }
             else if (want < cur) { if (cur - want >= 2 || ++calm >= 8) { cap = want; calm = 0; invalidate_graph(c); } }
             else calm = 0;
         };
-        adapt(c->cap_li, c->calm_li, sel[SEL_NBLK_LI]);
-        adapt(c->cap_hi, c->calm_hi, sel[SEL_NBLK_HI]);
+        adapt(c->cap_li, c->calm_li, sel[SEL_K_LI]);
+        adapt(c->cap_hi, c->calm_hi, sel[SEL_K_HI]);
     }
     if (sel_host) memcpy(sel_host, sel, sizeof(sel));
     return sel[SEL_STATUS];
@@ -1147,7 +1154,7 @@ extern "C" int rslam_k_rank_update(rslam_ctx* c, int32_t n, int32_t r, const dou
     const int NP = round_up(n, 64), K = round_up(r, TG_KC_HOST);
     if (lda < NP || ldc < NP || ldy < NP) return RSLAM_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc, tile_order(c, NP), nullptr, 0);
+    launch_rank_update(c->stream, NP, dA, lda, dY, ldy, c->d_sel.p, 0, K, dC, ldc, tile_order(c, NP), nullptr, 0, nullptr);
     HIPCHK(hipGetLastError());
     return RSLAM_OK;
 }
