@@ -1173,6 +1173,25 @@ sweep_step_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
     step_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, Linv + (long)step * 64 * 64, Yout, lds);
 }
 
+// Large systems (C5: 127 row blocks x 24 trailing columns): recomputing the panels in every tile would triple the
+// MFMA work of the sweep, so there the panel is solved once (panel_kernel, in place) and this launch holds the
+// trailing update of step k plus the factorisation of diagonal block k+1 (cd_factor_block, pending = 1).
+__global__ void __launch_bounds__(CD_THREADS)
+trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
+                  int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int nblk = sel[slot_nblk];
+    if (step + 1 >= nblk) return;                                 // no trailing matrix left
+    if (blockIdx.x == 0) {
+        cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 1);
+        return;
+    }
+    if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
+    const int b = blockIdx.x - 1;
+    trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
+}
+
 // dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
 constexpr size_t CD_STAGE_BYTES = sizeof(double) * (64 * CD_LD + 2 * 64 * CD_OPLD);      // Lf + the two staged operands
 constexpr size_t cd_max(size_t a, size_t b) { return a > b ? a : b; }
@@ -1201,10 +1220,13 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }
 
-// One stream: diag(0), then ONE launch per block step (sweep_step_kernel).
+// One stream: diag(0), then ONE launch per block step (sweep_step_kernel); for large systems (more than 512 tile
+// workgroups at the first step) panel(k) + trail_diag(k) instead, see trail_diag_kernel.
 // RSLAM_SWEEP_UNFUSED=1 selects the three-kernels-per-step sequence (diag(k) panel(k) trail(k)) for
 // measurement.  A two-stream lookahead variant (aux != nullptr) is kept for measurement only:
 // on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the trailing kernels
@@ -1221,6 +1243,18 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
     const bool two = (aux != nullptr && ev != nullptr);
     static const bool unfused = getenv("RSLAM_SWEEP_UNFUSED") != nullptr;
+    if (!two && !unfused && (long)row_blocks * steps > 512) {
+        // large system: panel once per step, then trailing update + next diagonal block in one launch
+        if (steps <= 0) return A;
+        chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
+        for (int step = 0; step < steps; ++step) {
+            panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
+            if (step + 1 < steps)
+                trail_diag_kernel<<<dim3(1 + row_blocks * (steps - step - 1)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
+                    A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+        }
+        return A;
+    }
     if (!two && !unfused) {
         if (steps <= 0) return Ystore;
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
