@@ -8,7 +8,7 @@
 //     best_mask_kernel      inlier set of the winner -> flags + ordered list
 // K6  gather_w/prepare      stacked system [S; P*H^T; nu^T]
 // K8  chol_diag/panel/trail blocked right-looking Cholesky sweep (MFMA)
-// K9  xupdate/quat          x + Y u, quaternion normalisation
+
 // K10 rank_update_kernel    P - Y Y^T with symmetrisation (MFMA, lower-triangle tile pairs)
 // K11 quat_cov_kernel       Jnorm congruence on rows/cols 3..6
 // K12 rescue_gate_kernel    chi-square gate of the high-innovation candidates
