@@ -2,15 +2,15 @@
 //
 // K1  predict_kernel        h_i, visibility, compact Jacobians, S_i
 // K2  pht_kernel            P*H^T exploiting the 13 structurally non-zero columns (HBM-bound)
-// K3  innov_kernel          w_i = S_i^-1 (z_i - h_i)
+// K3  (in pht_kernel)       w_i = S_i^-1 (z_i - h_i)
 // K4  score_kernel          hypothesis x feature inlier scoring (wave ballot/popcount)
-// K5  select_kernel         replay of the sequential best/adaptive-n_hyp scan
-//     best_mask_kernel      inlier set of the winner -> flags + ordered list
-// K6  gather_w/prepare      stacked system [S; P*H^T; nu^T]
-// K8  chol_diag/panel/trail blocked right-looking Cholesky sweep (MFMA)
-
+// K5  best_mask_kernel      replay of the sequential best/adaptive-n_hyp scan, inlier set of the winner
+// K6  prepare_system_kernel stacked system [S; P*H^T; nu^T]
+// K8  chol_diag_kernel, sweep_step_kernel (large systems: panel_kernel + trail_diag_kernel)
+//                           blocked right-looking Cholesky sweep, one launch per block step
+// K9  xupdate_rows          x + Y u, quaternion normalisation, Jnorm (first workgroups of K10's launch)
 // K10 rank_update_kernel    P - Y Y^T with symmetrisation (MFMA, lower-triangle tile pairs)
-// K11 quat_cov_kernel       Jnorm congruence on rows/cols 3..6
+// K11 (K10's epilogue)      Jnorm congruence on rows/cols 3..6
 // K12 rescue_gate_kernel    chi-square gate of the high-innovation candidates
 #include "kernels.h"
 #include "tile_gemm.h"
