@@ -16,6 +16,8 @@
 #include "tile_gemm.h"
 #include <vector>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rslam {
 
@@ -403,6 +405,7 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
         const int nblk = (2 * s_running + 63) / 64;
         sel[SEL_K_LI] = s_running;
         sel[SEL_NBLK_LI] = nblk;
+        sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
         if (nblk > cap_blocks) atomicMin(sel + SEL_STATUS, STATUS_SWEEP_CAP);   // launch sequence too short: re-run
     }
 }
@@ -1665,6 +1668,11 @@ int init_kernel_attributes2()
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (getenv("RSLAM_DEBUG_OCCUPANCY")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(rank_update_kernel), 256, (size_t)bytes);
+        fprintf(stderr, "[rslam] rank_update_kernel: %d workgroups per CU at %d B of dynamic LDS\n", nb, bytes);
+    }
     return (int)e;
 }
 
