@@ -234,7 +234,23 @@ def main():
             b_score = H_total * m * 96.0
             out["score_kernel"] = {"bound": "hbm", "algorithmic_bytes": b_score, "launch_us": acc["score_us"],
                                    "achieved_GBps": b_score / (acc["score_us"] * 1e-6) * 1e-9 if acc["score_us"] > 0 else 0,
-                                   "peak_GBps": HBM_PEAK_GBPS}
+                                   "peak_GBps": HBM_PEAK_GBPS,
+                                   "pairs_per_s_scoring_only": H_total * m / (acc["score_us"] * 1e-6) if acc["score_us"] > 0 else 0}
+            # the same kernel with 16 frames' worth of hypotheses in one grid, so that the figure is not one launch latency
+            # (SURVEY 8d): a second context with 16 H draws on the same frame, scoring stage timed by its stage events
+            big = RslamHip(cfg, device=local_rank)
+            rng16 = np.random.default_rng(99)
+            big.load_frame(frame.types, frame.x_pred, frame.P_pred, frame.z, ic, rng16.random(16 * H_total))
+            big.enable_timing(True)
+            t16 = []
+            for _ in range(6):
+                big.step_frame(False); big.sync()
+                t16.append(big.timings()["score_us"])
+            big.close()
+            us16 = float(np.median(t16[1:]))
+            out["score_kernel"]["x16_batched"] = {"hypotheses": 16 * H_total, "launch_us": us16,
+                                                  "achieved_GBps": 16 * b_score / (us16 * 1e-6) * 1e-9 if us16 > 0 else 0,
+                                                  "pairs_per_s": 16 * H_total * m / (us16 * 1e-6) if us16 > 0 else 0}
     if rank == 0 and world == 1 and not args.no_extras:
         # drop-in API: P uploaded by rslam_predict and downloaded by rslam_ransac_update every frame (PCIe inclusive)
         t_drop = []
