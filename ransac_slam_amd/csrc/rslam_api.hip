@@ -435,13 +435,13 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     if (ev_f0 >= 0) mark(c, ev_f0);
     const double* Ysys = c->d_A.p;        // the system whose lower rows hold Y = P H^T L^-T and u^T after the sweep
     {
+        static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // two-stream variant, measured slower: off
         const size_t need = 2 * (size_t)(c->RP / 64 + 1);
-        while (c->sweep_ev.size() < need) {
+        while (want_lookahead && c->sweep_ev.size() < need) {
             hipEvent_t e;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
             c->sweep_ev.push_back(e);
         }
-        static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // measured slower: off
         const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
         Ysys = launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk,
                                    cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS);
