@@ -1048,7 +1048,7 @@ panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     const int b = blockIdx.x;
     if (!row_block_active(b, step, nblk, rp_blocks)) return;
     double* tile = A + (long)b * 64 + (long)step * 64 * ldA;
-    d4 acc[2][2];
+    TgAcc acc;
     tg_zero(acc);
     tile_gemm_nt(tile, ldA, Linv + (long)step * 64 * 64, 64, 64, lds, acc);   // X * Linv^T
     tg_acc_to_lds(acc, lds, 1.0);
@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void trail_tile(double* __restrict__ A, long ldA, int
     double cin[16];                                   // the tile to update: in flight under the product
 #pragma unroll
     for (int q = 0; q < 16; ++q) cin[q] = C[row + (long)(g + 4 * q) * ldA];
-    d4 acc[2][2];
+    TgAcc acc;
     tg_zero(acc);
     tile_gemm_nt(Ai, ldA, Aj, ldA, 64, lds, acc);
     tg_acc_to_lds(acc, lds, 1.0);
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void step_tile(double* __restrict__ A, long ldA, int 
     tg_fill64(Linv_k, 64, bufB);
     if (two) tg_fill64(A + (long)j * 64 + (long)step * 64 * ldA, ldA, bufC);
     __syncthreads();
-    d4 yi[2][2], yj[2][2];
+    TgAcc yi, yj;
     tg_zero(yi);
     tg_gemm64_lds(bufA, bufB, yi);                    // Y_i = A(i,k) Linv^T
     __builtin_amdgcn_sched_barrier(0);                // keep the two products' LDS prefetch windows apart (register pressure)
@@ -1145,7 +1145,7 @@ __device__ __forceinline__ void step_tile(double* __restrict__ A, long ldA, int 
         for (int q = 0; q < 16; ++q) { const int c = g + 4 * q; Yi[row + (long)c * ldA] = bufA[c * TG_LD + row]; }
     }
     if (!has_col) return;
-    d4 acc[2][2];
+    TgAcc acc;
     tg_zero(acc);
     tg_gemm64_lds(bufA, Yj, acc);                     // Y_i Y_j^T
     __syncthreads();
@@ -1389,7 +1389,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         }
         return;
     }
-    d4 acc[2][2];
+    TgAcc acc;
     tg_zero(acc);
     tile_gemm_nt(Y + (long)bi * 64, ldy, Y + (long)bj * 64, ldy, K, lds, acc);
     double* Cs = lds;
@@ -1642,7 +1642,7 @@ gemm_nt_kernel(int K, double alpha, const double* __restrict__ A, long lda, cons
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int bi = blockIdx.x, bj = blockIdx.y;
-    d4 acc[2][2];
+    TgAcc acc;
     tg_zero(acc);
     tile_gemm_nt(A + (long)bi * 64, lda, B + (long)bj * 64, ldb, K, lds, acc);
     tg_acc_to_lds(acc, lds, alpha);

@@ -43,6 +43,17 @@ constexpr int TG_THREADS = 256;
 constexpr int TG_OPER_DOUBLES = TG_KC * TG_LD;              // one operand, one buffer
 constexpr int TG_LDS_DOUBLES = 4 * TG_OPER_DOUBLES;         // A,B x 2 buffers = 80 KiB
 
+// Sub-tile of a wave: TG_MI x TG_NI tiles of 16 x 16.  The B fragment of a 16-column tile has to be read four
+// times (block rotations), the A fragment of a 16-row tile once, so a tall, narrow wave tile reads less LDS per
+// MFMA: 2 x 2 (waves 2 x 2) = 10 reads per 16 MFMAs, 4 x 1 (waves 1 x 4) = 8.
+#if defined(TG_LAYOUT_2X2)
+constexpr int TG_MI = 2, TG_NI = 2;
+#else
+constexpr int TG_MI = 4, TG_NI = 1;
+#endif
+constexpr int TG_WN = 4 / TG_NI;   // waves along N
+typedef d4 TgAcc[TG_MI][TG_NI];
+
 constexpr int TG_NQ = TG_KC / 8;   // 16-byte loads per thread, operand and chunk
 struct TileRegs { d2 a[TG_NQ]; d2 b[TG_NQ]; };
 
@@ -111,39 +122,49 @@ __device__ __forceinline__ void tg_mma_16x16x4(double a, const BFrag& b, d4& acc
 // of each B fragment are read straight from LDS with rotated per-lane addresses (an LDS read
 // is asynchronous; the DPP alternative costs 12 VALU issues per k-step on the same SIMD the
 // MFMAs issue from -- measured 15 % slower).
-__device__ __forceinline__ void tg_compute_chunk(const double* As, const double* Bs, d4 (&acc)[2][2])
+__device__ __forceinline__ void tg_compute_chunk(const double* As, const double* Bs, TgAcc& acc)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / TG_WN, wn = wave % TG_WN;
     const int kq = lane >> 4, ij = lane & 15;
-    const double* ap = As + kq * TG_LD + wm * 32 + ij;
-    const double* bb = Bs + kq * TG_LD + wn * 32;
+    const double* ap = As + kq * TG_LD + wm * 16 * TG_MI + ij;
+    const double* bb = Bs + kq * TG_LD + wn * 16 * TG_NI;
     const double* bp0 = bb + ij;
     const double* bp1 = bb + ((ij - 4) & 15);
     const double* bp2 = bb + ((ij - 8) & 15);
     const double* bp3 = bb + ((ij - 12) & 15);
-    double a0 = ap[0], a1 = ap[16];
-    BFrag b0 = { bp0[0], bp1[0], bp2[0], bp3[0] }, b1 = { bp0[16], bp1[16], bp2[16], bp3[16] };
+    double a[TG_MI];
+    BFrag b[TG_NI];
+#pragma unroll
+    for (int mi = 0; mi < TG_MI; ++mi) a[mi] = ap[16 * mi];
+#pragma unroll
+    for (int ni = 0; ni < TG_NI; ++ni) b[ni] = BFrag{ bp0[16 * ni], bp1[16 * ni], bp2[16 * ni], bp3[16 * ni] };
 #pragma unroll
     for (int kk = 0; kk < TG_KC; kk += 4) {
-        double na0 = 0, na1 = 0;
-        BFrag nb0 = {0, 0, 0, 0}, nb1 = {0, 0, 0, 0};
+        double na[TG_MI];
+        BFrag nb[TG_NI];
         if (kk + 4 < TG_KC) {
 #if defined(TG_EXP_NO_LDS_READ)
             const int o = 0;
 #else
             const int o = (kk + 4) * TG_LD;
 #endif
-            na0 = ap[o]; na1 = ap[o + 16];
-            nb0.r0 = bp0[o]; nb0.r1 = bp1[o]; nb0.r2 = bp2[o]; nb0.r3 = bp3[o];
-            nb1.r0 = bp0[o + 16]; nb1.r1 = bp1[o + 16]; nb1.r2 = bp2[o + 16]; nb1.r3 = bp3[o + 16];
+#pragma unroll
+            for (int mi = 0; mi < TG_MI; ++mi) na[mi] = ap[o + 16 * mi];
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) nb[ni] = BFrag{ bp0[o + 16 * ni], bp1[o + 16 * ni], bp2[o + 16 * ni], bp3[o + 16 * ni] };
         }
-        tg_mma_16x16x4(a0, b0, acc[0][0]);
-        tg_mma_16x16x4(a0, b1, acc[0][1]);
-        tg_mma_16x16x4(a1, b0, acc[1][0]);
-        tg_mma_16x16x4(a1, b1, acc[1][1]);
-        if (kk + 4 < TG_KC) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+#pragma unroll
+        for (int mi = 0; mi < TG_MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) tg_mma_16x16x4(a[mi], b[ni], acc[mi][ni]);
+        if (kk + 4 < TG_KC) {
+#pragma unroll
+            for (int mi = 0; mi < TG_MI; ++mi) a[mi] = na[mi];
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) b[ni] = nb[ni];
+        }
     }
 }
 
@@ -152,7 +173,7 @@ __device__ __forceinline__ void tg_compute_chunk(const double* As, const double*
 // Ends with a barrier: lds may be reused by the caller immediately.
 __device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ A, long lda,
                                              const double* __restrict__ B, long ldb,
-                                             int K, double* lds, d4 (&acc)[2][2])
+                                             int K, double* lds, TgAcc& acc)
 {
     double* As0 = lds;
     double* Bs0 = lds + TG_OPER_DOUBLES;
@@ -189,12 +210,12 @@ __device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ A, long 
     }
 }
 
-__device__ __forceinline__ void tg_zero(d4 (&acc)[2][2])
+__device__ __forceinline__ void tg_zero(TgAcc& acc)
 {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TG_MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TG_NI; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 }
 
 // Spill the accumulators into an LDS tile Cs[col][row] (ld = TS_LD) so that the
@@ -204,20 +225,20 @@ constexpr int TS_DOUBLES = 64 * TS_LD;
 static_assert(TG_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 tiles in the operand buffers");
 
 template <int LD = 65>
-__device__ __forceinline__ void tg_acc_to_lds(const d4 (&acc)[2][2], double* Cs, double scale)
+__device__ __forceinline__ void tg_acc_to_lds(const TgAcc& acc, double* Cs, double scale)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / TG_WN, wn = wave % TG_WN;
     const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TG_MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < TG_NI; ++ni)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int row = wm * 32 + mi * 16 + 4 * blk + i;
-                const int col = wn * 32 + ni * 16 + 4 * ((blk - t) & 3) + j;
+                const int row = (wm * TG_MI + mi) * 16 + 4 * blk + i;
+                const int col = (wn * TG_NI + ni) * 16 + 4 * ((blk - t) & 3) + j;
                 Cs[col * LD + row] = acc[mi][ni][t] * scale;
             }
 }
@@ -236,7 +257,7 @@ __device__ __forceinline__ void tg_fill64(const double* __restrict__ G, long ldg
 
 // acc += A * B^T for two 64 x 64 operands already resident in LDS in operand layout ([k][TG_LD], i.e. a
 // 64 x 64 matrix stored column-major with leading dimension TG_LD spans two consecutive operand buffers)
-__device__ __forceinline__ void tg_gemm64_lds(const double* As, const double* Bs, d4 (&acc)[2][2])
+__device__ __forceinline__ void tg_gemm64_lds(const double* As, const double* Bs, TgAcc& acc)
 {
     tg_compute_chunk(As, Bs, acc);
     tg_compute_chunk(As + TG_OPER_DOUBLES, Bs + TG_OPER_DOUBLES, acc);
