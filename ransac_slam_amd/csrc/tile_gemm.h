@@ -138,8 +138,13 @@ __device__ __forceinline__ void tg_compute_chunk(const double* As, const double*
     BFrag b[TG_NI];
 #pragma unroll
     for (int mi = 0; mi < TG_MI; ++mi) a[mi] = ap[16 * mi];
+#if defined(TG_ROT_DPP)
+#pragma unroll
+    for (int ni = 0; ni < TG_NI; ++ni) b[ni] = tg_rotations(bp0[16 * ni]);
+#else
 #pragma unroll
     for (int ni = 0; ni < TG_NI; ++ni) b[ni] = BFrag{ bp0[16 * ni], bp1[16 * ni], bp2[16 * ni], bp3[16 * ni] };
+#endif
 #pragma unroll
     for (int kk = 0; kk < TG_KC; kk += 4) {
         double na[TG_MI];
@@ -152,8 +157,13 @@ __device__ __forceinline__ void tg_compute_chunk(const double* As, const double*
 #endif
 #pragma unroll
             for (int mi = 0; mi < TG_MI; ++mi) na[mi] = ap[o + 16 * mi];
+#if defined(TG_ROT_DPP)
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) nb[ni] = tg_rotations(bp0[o + 16 * ni]);
+#else
 #pragma unroll
             for (int ni = 0; ni < TG_NI; ++ni) nb[ni] = BFrag{ bp0[o + 16 * ni], bp1[o + 16 * ni], bp2[o + 16 * ni], bp3[o + 16 * ni] };
+#endif
         }
 #pragma unroll
         for (int mi = 0; mi < TG_MI; ++mi)
