@@ -49,7 +49,7 @@ def pmc_traffic_bytes(kernel_substr):
         return None
 
 
-def cpu_baseline(frame, cfg, sample_iters):
+def cpu_baseline(frame, cfg, sample_iters, seed):
     """Reference-structure CPU restatement (oracle, kind 'port'), 1 thread, bounded sample:
     full predict + `sample_iters` of the H RANSAC iterations + both full updates;
     the RANSAC part is scaled to H iterations (every iteration costs the same)."""
@@ -73,7 +73,32 @@ def cpu_baseline(frame, cfg, sample_iters):
     o2.predict(frame.types, frame.x_pred, frame.P_pred)
     o2.ransac_update(frame.z, ic, frame.draws)
     t5 = time.perf_counter()
+    # ... and the same on every host core: the OpenMP build of the oracle (identical results), in a child process
+    omp_ms, omp_threads = None, None
+    omp_lib = os.path.join(ROOT, "oracle", "_build", "librslam_oracle_omp.so")
+    if os.path.exists(omp_lib):
+        import subprocess
+        code = ("import sys, time, numpy as np; sys.path.insert(0, %r)\n"
+                "from oracle import pyoracle as po\n"
+                "from ransac_slam_amd import default_config\n"
+                "from ransac_slam_amd.synth import make_frame\n"
+                "fr = make_frame(L=%d, H=%d, seed=%d)\n"
+                "cfg = default_config(compat=%d, adaptive=0)\n"
+                "o = po.Oracle(cfg, structure=1)\n"
+                "ts = []\n"
+                "for _ in range(2):\n"
+                "    t = time.perf_counter(); h, vis, S = o.predict(fr.types, fr.x_pred, fr.P_pred)\n"
+                "    o.ransac_update(fr.z, (fr.ic & vis).astype(np.uint8), fr.draws); ts.append(time.perf_counter() - t)\n"
+                "print(min(ts) * 1e3)\n") % (ROOT, frame.L, len(frame.draws), seed, cfg.compat)
+        omp_threads = int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1)))   # a one-GPU box's CPU share
+        env = dict(os.environ, RSLAM_ORACLE_LIB=omp_lib, OMP_NUM_THREADS=str(omp_threads))
+        try:
+            omp_ms = float(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                                          timeout=120, check=True).stdout.strip().splitlines()[-1])
+        except Exception:                              # a baseline extra: never fail the bench line over it
+            omp_ms, omp_threads = None, None
     return dict(value=H * m / est_frame_s, unit="hypotheses*features/s", cores=1, kind="port",
+                optimised_cpu_all_cores_ms_per_frame=omp_ms, optimised_cpu_all_cores_threads=omp_threads,
                 optimised_cpu_ms_per_frame=(t5 - t4) * 1e3,
                 optimised_cpu_note="oracle structure=1 (structured H, cached hypotheses), 1 thread; not the reference's structure",
                 sample=(f"oracle/rslam_oracle.c (reference-structure mode, gcc -O2, 1 thread) on the same frame: "
@@ -265,7 +290,7 @@ def main():
         # widened rows of SURVEY 8(f), timed beside their oracle restatements (host calls incl. transfers + sync)
         out["widened_rows"] = widened_rows(ctx, frame)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(frame, default_config(compat=args.compat, adaptive=0), args.cpu_sample_iters)
+        out["cpu_baseline"] = cpu_baseline(frame, default_config(compat=args.compat, adaptive=0), args.cpu_sample_iters, wl["seed"])
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

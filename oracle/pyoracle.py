@@ -13,7 +13,8 @@ import numpy as np
 from ransac_slam_amd.ctypes_defs import Config, Layout, make_layout
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "librslam_oracle.so")
+# RSLAM_ORACLE_LIB selects another build of the same source (the OpenMP one, `make -C oracle omp`)
+_LIB_PATH = os.environ.get("RSLAM_ORACLE_LIB", os.path.join(_HERE, "_build", "librslam_oracle.so"))
 _lib = None
 
 _dp = C.POINTER(C.c_double)
