@@ -592,7 +592,7 @@ struct CdShared {
 };
 
 #if defined(CD_STAMPS)   // diagnostic build: where do the cycles of a pivot step go (never in the product build)
-__device__ unsigned long long g_cd_stamps[8];
+__device__ unsigned long long g_cd_stamps[16];
 #define CD_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #define CD_ACC_T(slot, a, b, tid) do { if (threadIdx.x == (tid)) g_cd_stamps[slot] += (b) - (a); } while (0)
 #define CD_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
@@ -911,6 +911,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
     double* Lout = Linv + (long)step * 64 * 64;
+    CD_STAMP(pr0);
     // T waves: the two tiles of the block they own, read first so that the latency hides under what follows
     d4 tacc[CD_TT];
 #pragma unroll
@@ -943,6 +944,8 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             Lop[m * CD_OPLD + row] = Lg[row + 64 * m];
         }
         __syncthreads();
+        CD_STAMP(pr1);
+        CD_ACC_T(8, pr0, pr1, 0);
         if (wave < 8) {
             const int l = t & 63, lr = l >> 4, lc = l & 15;
 #pragma unroll
@@ -958,7 +961,10 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             }
         }
         __syncthreads();
+        CD_STAMP(pr2);
+        CD_ACC_T(9, pr1, pr2, 0);
     }
+    CD_STAMP(pr3);
     {
         const int row = t & 63, g = t >> 6;
         if (pending == 1) {
@@ -980,8 +986,12 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             for (int c = g; c < 64; c += 2) { sh.Lf[c * CD_LD + row] = 0.0; sh.Mf[c * CD_LD + row] = 0.0; }
         }
         __syncthreads();                                             // (C)
+        CD_STAMP(pr4);
+        CD_ACC_T(10, pr3, pr4, 0);
         if (wave == 0) cd_panel_wave(sh, n_piv4);
         else cd_inverse_wave(sh, n_piv4);
+        CD_STAMP(pr5);
+        CD_ACC_T(11, pr4, pr5, 0);
     } else {
         switch (wave) {
         case 2: cd_t_wave<0>(sh, n_piv4, tacc, pending); break;
@@ -1006,6 +1016,9 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             if (i >= c) tile[i + (long)c * ldA] = lv;
         }
     }
+    CD_STAMP(pr6);
+    CD_ACC_T(12, pr0, pr6, 0);
+    if (t == 0) { CD_ACC_T(13, pr0, pr0 + 1, 0); }
     if (bad) atomicMin(status, -6);                              // RSLAM_ERR_NOT_SPD
     if (t == 0 && sh.timeout) atomicMin(status, -3);             // RSLAM_ERR_HIP: hand-over protocol broke (never expected)
 }
@@ -1205,8 +1218,8 @@ static_assert(offsetof(CdShared, Mf) == sizeof(double) * 64 * CD_LD, "the staged
 #if defined(CD_STAMPS)
 int debug_read_cd_stamps(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_stamps), 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cd_stamps), z, 64) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_stamps), 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cd_stamps), z, 128) != hipSuccess) return -1; }
     return 0;
 }
 #endif
