@@ -899,23 +899,19 @@ __device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
     }
 }
 
-__device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
-                                                const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
-                                                int32_t* __restrict__ status, int pending)
+// Global reads of one diagonal block, issued before anything else so that they can fly while the frame scalars
+// (sel[]) are still being fetched: the block's own tiles (T waves) and, for the single-launch step, the operands
+// of its panel row.
+struct CdPre { d4 tacc[CD_TT]; double a[64 / (CD_THREADS / 64)], l[64 / (CD_THREADS / 64)]; };
+
+__device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict__ A, long ldA, int step,
+                                           const double* __restrict__ Linv, int pending)
 {
-    // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
-    // chain stops after the last real row, L and L^-1 are the identity there
-    const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
-    const int n_piv4 = (r_here + 3) >> 2;
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
-    double* Lout = Linv + (long)step * 64 * 64;
-    CD_STAMP(pr0);
-    // T waves: the two tiles of the block they own, read first so that the latency hides under what follows
-    d4 tacc[CD_TT];
+    const double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
 #pragma unroll
-    for (int o = 0; o < CD_TT; ++o) tacc[o] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int o = 0; o < CD_TT; ++o) pre.tacc[o] = (d4){0.0, 0.0, 0.0, 0.0};
     if (wave >= 2 && wave < 2 + CD_TW) {
         const int l = t & 63, lr = l >> 4, lc = l & 15;
 #pragma unroll
@@ -926,22 +922,49 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 16 * cd_tr(idx) + lr + 4 * reg, col = 16 * cd_tc(idx) + lc;
                 // the lower triangle of the global tile is authoritative; mirror it
-                tacc[o][reg] = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
+                pre.tacc[o][reg] = (row >= col) ? tile[row + (long)col * ldA] : tile[col + (long)row * ldA];
             }
         }
     }
+    if (pending == 2) {
+        const double* Ag = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
+        const double* Lg = Linv + (long)(step - 1) * 64 * 64;
+        const int row = t & 63, g = t >> 6;
+#pragma unroll
+        for (int q = 0; q < 64 / (CD_THREADS / 64); ++q) {
+            const int m = g + (CD_THREADS / 64) * q;
+            pre.a[q] = Ag[row + (long)m * ldA];
+            pre.l[q] = Lg[row + 64 * m];
+        }
+    }
+}
+
+__device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
+                                                const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
+                                                int32_t* __restrict__ status, int pending, const CdPre& pre)
+{
+    // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
+    // chain stops after the last real row, L and L^-1 are the identity there
+    const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
+    const int n_piv4 = (r_here + 3) >> 2;
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
+    double* Lout = Linv + (long)step * 64 * 64;
+    CD_STAMP(pr0);
+    const d4 (&tacc)[CD_TT] = pre.tacc;
     if (pending == 2) {
         // Single-launch block step: the panel row of THIS block for the previous column, X = A(k,k-1) Linv(k-1)^T,
         // is formed here (nobody else needs it: the tile workgroups of the same launch recompute the S-row panels
         // they use).  Operands staged behind Lf, over members that are initialised afterwards.
         double* Aop = sh.Mf;                         // [m][CD_OPLD] : A(k,k-1)(row, m)
         double* Lop = sh.Mf + 64 * CD_OPLD;          // [m][CD_OPLD] : Linv(k-1)(c, m)
-        const double* Ag = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
-        const double* Lg = Linv + (long)(step - 1) * 64 * 64;
         const int row = t & 63, g = t >> 6;
-        for (int m = g; m < 64; m += CD_THREADS / 64) {
-            Aop[m * CD_OPLD + row] = Ag[row + (long)m * ldA];
-            Lop[m * CD_OPLD + row] = Lg[row + 64 * m];
+#pragma unroll
+        for (int q = 0; q < 64 / (CD_THREADS / 64); ++q) {
+            const int m = g + (CD_THREADS / 64) * q;
+            Aop[m * CD_OPLD + row] = pre.a[q];
+            Lop[m * CD_OPLD + row] = pre.l[q];
         }
         __syncthreads();
         CD_STAMP(pr1);
@@ -1028,8 +1051,10 @@ chol_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __re
                  int slot_k, double* __restrict__ Linv, int32_t* __restrict__ status, int pending)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    CdPre pre;
+    cd_preload(pre, A, ldA, step, Linv, pending);                 // speculative: flies with the sel[] fetch
     if (step >= sel[slot_nblk]) return;
-    cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step, sel, slot_k, Linv, status, pending);
+    cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step, sel, slot_k, Linv, status, pending, pre);
 }
 
 // rows of block b participate in step `step` of a sweep with nblk column blocks?
@@ -1177,13 +1202,16 @@ sweep_step_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
                   int32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int nblk = sel[slot_nblk];
-    if (step >= nblk) return;
     if (blockIdx.x == 0) {
-        if (step + 1 < nblk)
-            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 2);
+        if (step + 1 >= rp_blocks) return;                        // no such block (and its tiles would be out of bounds)
+        CdPre pre;
+        cd_preload(pre, A, ldA, step + 1, Linv, 2);               // speculative: flies with the sel[] fetch
+        if (step + 1 < sel[slot_nblk])
+            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 2, pre);
         return;
     }
+    const int nblk = sel[slot_nblk];
+    if (step >= nblk) return;
     if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
     const int b = blockIdx.x - 1;
     step_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, Linv + (long)step * 64 * 64, Yout, lds);
@@ -1197,12 +1225,16 @@ trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
                   int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int nblk = sel[slot_nblk];
-    if (step + 1 >= nblk) return;                                 // no trailing matrix left
     if (blockIdx.x == 0) {
-        cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 1);
+        if (step + 1 >= rp_blocks) return;
+        CdPre pre;
+        cd_preload(pre, A, ldA, step + 1, Linv, 1);
+        if (step + 1 < sel[slot_nblk])
+            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 1, pre);
         return;
     }
+    const int nblk = sel[slot_nblk];
+    if (step + 1 >= nblk) return;                                 // no trailing matrix left
     if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
     const int b = blockIdx.x - 1;
     trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
