@@ -792,8 +792,11 @@ __device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const d4 (&a
     if (pending) {
         __syncthreads();                 // (A) the previous panel row is staged in Lf
         const double* Xg = sh.Lf;
+        // the update of a third tile (T waves 0 and 1 own three) is computed by the M wave of the same number, idle
+        // until the chain starts, and handed over through the (still unused) Ms buffers
+        constexpr int NP_ = NT > 2 ? 2 : NT;
 #pragma unroll
-        for (int o = 0; o < NT; ++o) {
+        for (int o = 0; o < NP_; ++o) {
             const int tr = cd_tr(B + CD_TW * o), tc = cd_tc(B + CD_TW * o);
 #pragma unroll 4
             for (int kk = 0; kk < 64; kk += 4)
@@ -801,6 +804,11 @@ __device__ __forceinline__ void cd_t_wave(CdShared& sh, int n_piv4, const d4 (&a
                                                               -Xg[(kk + lr) * CD_LD + 16 * tc + lc], acc[o], 0, 0, 0);
         }
         __syncthreads();                 // (B) Lf may be cleared
+        if (NT > 2) {
+            static_assert(CD_TT <= 3 && CD_MW >= 2, "third tiles go to M waves 0 and 1");
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[NT - 1][reg] += sh.Ms[B][reg * 64 + l];
+        }
     }
     // strip of pivot block 0
 #pragma unroll
@@ -866,7 +874,22 @@ __device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
             const int idx = C + CD_MW * o;
             acc[o][reg] = (16 * cd_tr(idx) + lr + 4 * reg == 16 * cd_tc(idx) + lc) ? 1.0 : 0.0;
         }
-    if (pending) { __syncthreads(); __syncthreads(); }   // (A), (B)
+    if (pending) {
+        __syncthreads();                                  // (A)
+        // pending update of trailing tile 2 * CD_TW + C on behalf of T wave C (see cd_t_wave)
+        constexpr int idx = 2 * CD_TW + C;
+        if (idx < 10) {
+            const double* Xg = sh.Lf;
+            d4 pacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int kk = 0; kk < 64; kk += 4)
+                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xg[(kk + lr) * CD_LD + 16 * cd_tr(idx) + lc],
+                                                            -Xg[(kk + lr) * CD_LD + 16 * cd_tc(idx) + lc], pacc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) sh.Ms[C][reg * 64 + l] = pacc[reg];
+        }
+        __syncthreads();                                  // (B)
+    }
     __syncthreads();                                      // (C)
 #pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
@@ -970,13 +993,15 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         CD_STAMP(pr1);
         CD_ACC_T(8, pr0, pr1, 0);
         if (wave < 8) {
+            // L^-1 is lower triangular: column tile tc of X only needs k < 16 (tc + 1).  Waves pair the column tiles
+            // {0,3} and {1,2} of one row tile: 20 MFMAs each instead of 32.
             const int l = t & 63, lr = l >> 4, lc = l & 15;
+            const int tr = wave >> 1;
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
-                const int tr = (2 * wave + o) >> 2, tc = (2 * wave + o) & 3;
+                const int tc = (wave & 1) ? 1 + o : 3 * o;
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-                for (int kk = 0; kk < 64; kk += 4)
+                for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[(kk + lr) * CD_OPLD + 16 * tr + lc],
                                                                Lop[(kk + lr) * CD_OPLD + 16 * tc + lc], acc, 0, 0, 0);
 #pragma unroll
