@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--compat", type=int, default=1, help="1 = reference-identical arithmetic (default), 0 = corrected")
     ap.add_argument("--dedup", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-sample-iters", type=int, default=40)
+    ap.add_argument("--cpu-sample-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
