@@ -218,6 +218,12 @@ int rslam_load_frame(rslam_ctx* ctx, const rslam_layout* layout,
                      const double* z, const uint8_t* ic,
                      const double* draws, int32_t n_draws);
 
+/* New measurements for the resident prior (a frame sequence whose covariance never leaves HBM):
+ * z / ic / draws as for rslam_ransac_update, uploaded into the context's buffers; the gather tables
+ * that replace Converter::find/select (Converter.cpp:210-287) are rebuilt.  Returns after the upload. */
+int rslam_load_measurements(rslam_ctx* ctx, const double* z, const uint8_t* ic,
+                            const double* draws, int32_t n_draws);
+
 /* Segment 1 on the resident frame. */
 int rslam_step_predict(rslam_ctx* ctx);
 
@@ -238,6 +244,11 @@ int rslam_step_frame(rslam_ctx* ctx, int32_t use_graph);
  * exchanges the supports (e.g. RCCL all-gather) between the two.  d_supports is a DEVICE pointer. */
 int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t hyp_end,
                      int32_t* d_supports, int32_t use_graph);
+
+/* Diagnostics of the resident pipeline since rslam_create (any pointer may be NULL): hipGraph captures
+ * (a change of the launch sequence re-captures), update stages that had to be re-run because the
+ * factor sweep had been enqueued too short for the frame's inlier count. */
+int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 
 /* Block until the stream is idle; returns the device-side status of the
  * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...). */

@@ -46,6 +46,8 @@ SYMBOLS = {
     "rslam_timings": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
     "rslam_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rslam_load_frame": (C.c_int, [C.c_void_p, C.POINTER(Layout), _dp, _dp, _dp, _u8p, _dp, C.c_int32]),
+    "rslam_load_measurements": (C.c_int, [C.c_void_p, _dp, _u8p, _dp, C.c_int32]),
+    "rslam_get_counters": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "rslam_step_predict": (C.c_int, [C.c_void_p]),
     "rslam_step_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rslam_step_update": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -273,6 +275,18 @@ class RslamHip:
         draws = np.ascontiguousarray(draws, dtype=np.float64)
         _chk(lib().rslam_load_frame(self._h, C.byref(lay), _p(x), _p(P), _p(z), _p(ic, _u8p), _p(draws), len(draws)),
              "rslam_load_frame")
+
+    def load_measurements(self, z, ic, draws):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        ic = np.ascontiguousarray(ic, dtype=np.uint8)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        self.H = len(draws)
+        _chk(lib().rslam_load_measurements(self._h, _p(z), _p(ic, _u8p), _p(draws), len(draws)), "rslam_load_measurements")
+
+    def counters(self):
+        a, b = C.c_int32(), C.c_int32()
+        _chk(lib().rslam_get_counters(self._h, C.byref(a), C.byref(b)), "rslam_get_counters")
+        return dict(graph_captures=a.value, sweep_reruns=b.value)
 
     def step_predict(self):
         _chk(lib().rslam_step_predict(self._h), "rslam_step_predict")

@@ -12,11 +12,11 @@ namespace rslam {
 enum SelSlot {
     SEL_BEST_HYP = 0, SEL_BEST_SUPPORT = 1, SEL_HYPS_EVALUATED = 2,
     SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7, SEL_XU_FLAG = 8,
+    SEL_CAP_FLAG = 9,        // != 0: the captured launch sequence of a factor sweep was shorter than the inlier count
+                             // needs; the host re-runs the update stage with the full-length sequence
+    SEL_STATUS_FRONT = 10,   // status of the prediction / scoring stage (kept when only the update stage is re-run)
     SEL_COUNT = 16
 };
-// internal device status: the captured launch sequence of a factor sweep was shorter than the
-// inlier count needs (the host re-runs the update stage with the full-length sequence)
-constexpr int STATUS_SWEEP_CAP = -100;
 
 constexpr int TG_KC_HOST = 32;   // K granularity of the MFMA tile engine (tile_gemm.h TG_KC)
 

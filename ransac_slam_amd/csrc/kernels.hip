@@ -406,7 +406,7 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
         sel[SEL_K_LI] = s_running;
         sel[SEL_NBLK_LI] = nblk;
         sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
-        if (nblk > cap_blocks) atomicMin(sel + SEL_STATUS, STATUS_SWEEP_CAP);   // launch sequence too short: re-run
+        if (nblk > cap_blocks) sel[SEL_CAP_FLAG] = 1;   // launch sequence too short: re-run
     }
 }
 
@@ -455,7 +455,7 @@ rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restr
         const int nblk = (2 * s_running + 63) / 64;
         sel[SEL_K_HI] = s_running;
         sel[SEL_NBLK_HI] = nblk;
-        if (nblk > cap_blocks) atomicMin(sel + SEL_STATUS, STATUS_SWEEP_CAP);
+        if (nblk > cap_blocks) sel[SEL_CAP_FLAG] = 1;
     }
 }
 

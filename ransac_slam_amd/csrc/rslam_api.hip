@@ -103,7 +103,20 @@ struct rslam_ctx {
     int calm_li = 0, calm_hi = 0;
     const int32_t* last_sup = nullptr;
     int reruns = 0;
+    int graph_captures = 0;
+    bool sweep_can_overflow = false;   // the update stage in flight was enqueued with a shortened sweep ...
+    bool frame_checked = true;         // ... and read_status has (not) looked at it yet
 };
+
+// bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
+static void mark_update_enqueued(rslam_ctx* c, const int32_t* d_sup)
+{
+    const int rp_blocks = c->RP / 64;
+    c->last_sup = d_sup;
+    c->sweep_can_overflow = (c->cap_li < rp_blocks || c->cap_hi < rp_blocks);
+    c->frame_checked = false;
+    c->have_post = true;
+}
 
 static void invalidate_graph(rslam_ctx* c)
 {
@@ -113,6 +126,8 @@ static void invalidate_graph(rslam_ctx* c)
         c->graph_valid[k] = false;
     }
 }
+
+extern "C" int rslam_destroy(rslam_ctx* c);
 
 extern "C" const char* rslam_version(void) { return "rslam-hip 0.1 (gfx950)"; }
 
@@ -145,16 +160,19 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->cam.f = cfg->cam.f; c->cam.dx = cfg->cam.dx; c->cam.dy = cfg->cam.dy;
     c->cam.nRows = cfg->cam.nRows; c->cam.nCols = cfg->cam.nCols;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RSLAM_ERR_HIP; }
+    // every failure path below goes through rslam_destroy, which releases whatever exists so far
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->own_stream = nullptr; (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     c->stream = c->own_stream;
     if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
-    if (init_kernel_attributes() != 0 || init_kernel_attributes2() != 0) { (void)hipStreamDestroy(c->own_stream); delete c; return RSLAM_ERR_HIP; }
-    bool ok = true;
-    for (int i = 0; i < EV_COUNT; ++i) ok = ok && (hipEventCreate(&c->ev[i]) == hipSuccess);
-    c->ev_ok = ok;
+    if (init_kernel_attributes() != 0 || init_kernel_attributes2() != 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
+    int n_ev = 0;
+    for (; n_ev < EV_COUNT; ++n_ev) if (hipEventCreate(&c->ev[n_ev]) != hipSuccess) break;
+    c->ev_ok = (n_ev == EV_COUNT);
+    if (!c->ev_ok) for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     memset(&c->times, 0, sizeof(c->times));
-    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0) { delete c; return RSLAM_ERR_HIP; }
-    if (hipMemset(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT) != hipSuccess) { delete c; return RSLAM_ERR_HIP; }
+    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
+    if (hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     *out = c;
     return RSLAM_OK;
 }
@@ -163,7 +181,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
 {
     if (!c) return RSLAM_ERR_ARG;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     invalidate_graph(c);
     c->d_type.release(); c->d_vis.release(); c->d_hash.release(); c->d_hash2.release(); c->d_ic.release();
     c->d_li.release(); c->d_hi.release(); c->d_mtype.release();
@@ -381,7 +399,7 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     hipStream_t s = c->stream;
     if (!c->pht_done) {
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
-                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
+                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT);
         c->pht_done = true;
     }
     mark(c, EV_PHT);
@@ -467,10 +485,10 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     if (!d_sup) return RSLAM_ERR_ARG;
     hipStream_t s = c->stream;
     int32_t* sel = c->d_sel.p;
-    c->last_sup = d_sup;
+    mark_update_enqueued(c, d_sup);
     if (!c->pht_done) {   // update without a local score pass (supports came from elsewhere)
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
-                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS);
+                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT);
         c->pht_done = true;
     }
     // K5 consensus (Tracking.cpp:507-537)
@@ -499,7 +517,6 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);
-    c->have_post = true;
     return RSLAM_OK;
 }
 
@@ -519,12 +536,15 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     int rc = read_status_raw(c, sel);
     if (rc) return rc;
     const int rp_blocks = c->RP / 64;
-    if (sel[SEL_STATUS] == STATUS_SWEEP_CAP && c->last_sup) {
+    if (sel[SEL_CAP_FLAG] != 0 && c->last_sup) {
         c->cap_li = c->cap_hi = 1 << 20;
         invalidate_graph(c);
         ++c->reruns;
         const int timing = c->timing; c->timing = 0;
+        // everything the shortened update stage left behind is void (its rank update consumed columns the sweep never
+        // produced, so even a "not SPD" of the second pass may be spurious); the front-stage status is kept
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_CAP_FLAG, 0, sizeof(int32_t), c->stream));
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));     // Jnorm hand-over of the rank-update launches
         rc = enqueue_update(c, c->last_sup);
         c->timing = timing;
@@ -532,6 +552,7 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         rc = read_status_raw(c, sel);
         if (rc) return rc;
     }
+    if (sel[SEL_STATUS_FRONT] < sel[SEL_STATUS]) sel[SEL_STATUS] = sel[SEL_STATUS_FRONT];
     if (c->have_meas && c->last_sup && sel[SEL_STATUS] == 0) {
         // grow at once (an overflow costs a re-run of the update stage); shrink at once when two or more block
         // steps are wasted, and by the last one only after the count has stayed lower for 8 frames (each change
@@ -551,6 +572,7 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         adapt(c->cap_hi, c->calm_hi, sel[SEL_K_HI]);
     }
     if (sel_host) memcpy(sel_host, sel, sizeof(sel));
+    c->frame_checked = true;
     return sel[SEL_STATUS];
 }
 
@@ -761,11 +783,15 @@ extern "C" int rslam_set_posterior(rslam_ctx* c, const rslam_layout* layout, con
     return RSLAM_OK;
 }
 
+static int settle_posterior(rslam_ctx* c);
+
 extern "C" int rslam_ekf_prediction(rslam_ctx* c, double delta_t, double std_a, double std_alpha)
 {
     if (!c) return RSLAM_ERR_ARG;
-    if (!c->have_post) return RSLAM_ERR_STATE;
-    HIPCHK(hipSetDevice(c->device));
+    // a frame whose factor sweep may have been enqueued too short must be checked (and re-run) before its
+    // posterior becomes the next prior: the next predict_kernel would erase the overflow flag
+    const int rc = settle_posterior(c);
+    if (rc) return rc;
     hipStream_t s = c->stream;
     const size_t nn = (size_t)c->NP * c->NP;
     HIPCHK(hipMemcpyAsync(c->d_xpred.p, c->d_x2.p, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
@@ -779,20 +805,21 @@ extern "C" int rslam_ekf_prediction(rslam_ctx* c, double delta_t, double std_a, 
 // ------------------------------------------------------------------------
 // Map::map_management state surgery on the resident posterior
 // ------------------------------------------------------------------------
-namespace {
-
-// a frame whose update stage is still in flight must have completed (and possibly been re-run,
-// see read_status) before its posterior is edited
-int settle_posterior(rslam_ctx* c)
+// A frame whose update stage is still in flight must have completed (and possibly been re-run, see
+// read_status) before its posterior is edited, propagated or fetched.  Frames whose sweep cannot
+// overflow (persistent sweep, or caps at full length) need no host round trip.
+static int settle_posterior(rslam_ctx* c)
 {
     if (!c->have_post) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
-    if (c->have_meas && c->last_sup) {
+    if (c->have_meas && c->last_sup && c->sweep_can_overflow && !c->frame_checked) {
         const int st = read_status(c, nullptr);
         if (st < 0) return st;
     }
     return RSLAM_OK;
 }
+
+namespace {
 
 // Runs the congruence into the scratch pair (d_xpred, d_Ppred), swaps it with the posterior
 // pair and installs the new layout.  mode 0 delete / 1 convert / 2 insert.
@@ -846,11 +873,14 @@ extern "C" int rslam_map_delete_feature(rslam_ctx* c, int32_t feature)
     const int w = c->h_type[feature] == RSLAM_FEAT_INVERSE_DEPTH ? 6 : 3;
     std::vector<uint8_t> type(c->h_type);
     type.erase(type.begin() + feature);
-    if ((int)c->h_slot.size() == c->L) {                           // the feature store follows features_info.erase (Map.cpp:27)
+    const bool has_store = ((int)c->h_slot.size() == c->L);
+    rc = apply_map_edit(c, 0, c->h_off[feature], 0, w, 0, 0, type, 0, 0.0, 0.0, 0.0, 0.0);
+    if (rc) return rc;
+    if (has_store) {                                               // the feature store follows features_info.erase (Map.cpp:27)
         c->free_slots.push_back(c->h_slot[feature]);
         c->h_slot.erase(c->h_slot.begin() + feature);
     }
-    return apply_map_edit(c, 0, c->h_off[feature], 0, w, 0, 0, type, 0, 0.0, 0.0, 0.0, 0.0);
+    return RSLAM_OK;
 }
 
 extern "C" int rslam_map_convert(rslam_ctx* c, double linearity_threshold, int32_t* converted, double* linearity)
@@ -928,8 +958,8 @@ extern "C" int rslam_fetch_prior(rslam_ctx* c, double* x_pred, double* P_pred)
 extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
 {
     if (!c || !P) return RSLAM_ERR_ARG;
-    if (!c->have_state && !c->have_post) return RSLAM_ERR_STATE;
-    HIPCHK(hipSetDevice(c->device));
+    const int rc = settle_posterior(c);          // RSLAM_ERR_STATE unless a posterior exists
+    if (rc) return rc;
     HIPCHK(hipMemcpy2DAsync(P, sizeof(double) * c->n, c->d_P.p, sizeof(double) * c->NP, sizeof(double) * c->n, c->n,
                             hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -939,8 +969,8 @@ extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
 extern "C" int rslam_fetch_state(rslam_ctx* c, double* x)
 {
     if (!c || !x) return RSLAM_ERR_ARG;
-    if (!c->have_state && !c->have_post) return RSLAM_ERR_STATE;
-    HIPCHK(hipSetDevice(c->device));
+    const int rc = settle_posterior(c);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(x, c->d_x2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return RSLAM_OK;
@@ -1004,6 +1034,23 @@ extern "C" int rslam_load_frame(rslam_ctx* c, const rslam_layout* layout, const 
     return upload_measurements(c, z, ic, draws, n_draws, false);
 }
 
+extern "C" int rslam_load_measurements(rslam_ctx* c, const double* z, const uint8_t* ic, const double* draws, int32_t n_draws)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (!c->have_state) return RSLAM_ERR_STATE;
+    // the posterior of a frame still in flight reads the measurement buffers: let it finish (and be checked) first
+    if (c->have_post && !c->frame_checked) { const int st = read_status(c, nullptr); if (st < 0) return st; }
+    return upload_measurements(c, z, ic, draws, n_draws, false);
+}
+
+extern "C" int rslam_get_counters(rslam_ctx* c, int32_t* graph_captures, int32_t* sweep_reruns)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (graph_captures) *graph_captures = c->graph_captures;
+    if (sweep_reruns) *sweep_reruns = c->reruns;
+    return RSLAM_OK;
+}
+
 extern "C" int rslam_step_predict(rslam_ctx* c)
 {
     if (!c) return RSLAM_ERR_ARG;
@@ -1048,6 +1095,7 @@ static int replay(rslam_ctx* c, int k, F enqueue)
         if (e != hipSuccess || !c->graph[k]) { ctx_last_hip_error = (int)e; return RSLAM_ERR_HIP; }
         HIPCHK(hipGraphInstantiate(&c->graph_exec[k], c->graph[k], nullptr, nullptr, 0));
         c->graph_valid[k] = true;
+        ++c->graph_captures;
     }
     HIPCHK(hipGraphLaunch(c->graph_exec[k], c->stream));
     return RSLAM_OK;
@@ -1061,7 +1109,8 @@ extern "C" int rslam_step_frame(rslam_ctx* c, int32_t use_graph)
     if (!use_graph || c->timing) return enqueue_frame(c);
     const int rc = replay(c, 0, [&]() { return enqueue_frame(c); });
     if (rc) return rc;
-    c->predicted = true; c->pht_done = true; c->last_sup = c->d_sup.p;
+    c->predicted = true; c->pht_done = true; c->patches_valid = false;
+    mark_update_enqueued(c, c->d_sup.p);
     return RSLAM_OK;
 }
 
@@ -1081,7 +1130,7 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
         }
         const int rc = replay(c, 1, work);
         if (rc) return rc;
-        c->predicted = true; c->pht_done = true;
+        c->predicted = true; c->pht_done = true; c->patches_valid = false;
         return RSLAM_OK;
     }
     if (!c->predicted) return RSLAM_ERR_STATE;
@@ -1090,7 +1139,7 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
     if (c->g2_sup != d_supports) { c->graph_valid[2] = false; c->g2_sup = d_supports; }
     const int rc = replay(c, 2, work);
     if (rc) return rc;
-    c->last_sup = d_supports; c->have_post = true;
+    mark_update_enqueued(c, d_supports);
     return RSLAM_OK;
 }
 

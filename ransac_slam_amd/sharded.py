@@ -51,6 +51,13 @@ class ShardedFrame:
 
     def step(self):
         """One frame: predict, score own slice, exchange, consensus + updates."""
+        ctx = getattr(self.engine, "stream_context", None)
+        if ctx is None:
+            return self._step()
+        with ctx():                               # kernels and the collective on ONE stream: ordered without host syncs
+            return self._step()
+
+    def _step(self):
         e = self.engine
         if hasattr(e, "step_phase"):              # engines that replay each half from a hipGraph
             e.step_phase(0, self.begin, self.end, self.local)
@@ -68,14 +75,27 @@ class ShardedFrame:
 
 
 class HipEngine:
-    """The product engine: ransac_slam_amd.api.RslamHip on this rank's GPU, enqueued
-    on torch's current stream so that the RCCL all-gather is ordered with the kernels."""
+    """The product engine: ransac_slam_amd.api.RslamHip on this rank's GPU.  Kernels and the RCCL
+    all-gather are enqueued on ONE torch stream, which orders them without host synchronisation.
+    torch's default stream has the handle 0, which rslam_set_stream reads as "use the context's own
+    stream" -- kernels would then run unordered with the collective -- so the engine never uses it:
+    unless the caller's current stream is a real side stream it creates and owns one, and
+    ShardedFrame.step() runs under it (stream_context)."""
 
-    def __init__(self, ctx, device_index: int, use_graph: bool = True):
+    def __init__(self, ctx, device_index: int, use_graph: bool = True, stream=None):
         self.ctx = ctx
         self.use_graph = use_graph
         self.device = torch.device("cuda", device_index)
-        ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        if stream is None:
+            cur = torch.cuda.current_stream(self.device)
+            stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device=self.device)
+        if stream.cuda_stream == 0:
+            raise ValueError("HipEngine needs a non-default torch stream")
+        self.stream = stream
+        ctx.set_stream(stream.cuda_stream)
+
+    def stream_context(self):
+        return torch.cuda.stream(self.stream)
 
     @property
     def H(self):

@@ -87,6 +87,8 @@ class Frame:
     draws: np.ndarray      # H
     x_true: np.ndarray
     outlier: np.ndarray    # bool L (ground truth)
+    diagD: np.ndarray = None   # P_pred = diag(diagD) + U U^T (kept so that further measurements can be drawn)
+    U: np.ndarray = None
 
     @property
     def L(self):
@@ -155,7 +157,21 @@ def make_frame(L=16, H=32, seed=0, frac_cartesian=0.0, frac_outlier=0.2, frac_ic
     ic = (rng.random(L) < frac_ic).astype(np.uint8)
     draws = rng.random(H)
     return Frame(types=types, offsets=offsets, n=n, x_pred=x, P_pred=P, z=np.ascontiguousarray(z),
-                 ic=ic, draws=draws, x_true=x_true, outlier=outlier)
+                 ic=ic, draws=draws, x_true=x_true, outlier=outlier, diagD=diagD, U=U)
+
+
+def remeasure(fr: Frame, seed, frac_outlier=0.2, meas_sigma=0.5, H=None, cam=None):
+    """Another frame's worth of measurements for the SAME prior (a sequence whose covariance stays
+    resident): a new truth ~ N(x_pred, P_pred), z = h(truth) + noise, a fraction of gross outliers,
+    new draws.  Returns (z, outlier, draws)."""
+    cam = cam or default_camera()
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + 0x0F00000 + seed))
+    x_true = fr.x_pred + np.sqrt(fr.diagD) * rng.normal(0, 1, fr.n) + fr.U @ rng.normal(0, 1, fr.U.shape[1])
+    h_true = project(cam, x_true, fr.types, fr.offsets)
+    outlier = rng.random(fr.L) < frac_outlier
+    z = h_true + rng.normal(0, meas_sigma, (fr.L, 2))
+    z[outlier] += rng.uniform(-10, 10, (int(outlier.sum()), 2))
+    return np.ascontiguousarray(z), outlier, rng.random(H if H is not None else len(fr.draws))
 
 
 def make_config_frame(config_id: int) -> Frame:
@@ -219,3 +235,29 @@ def make_feature_records(cam, fr, seed=0, pose_jitter=0.02):
         base = base[4:-4, 4:-4]
         patch_f[i] = np.clip(128.0 + 60.0 * base / base.std(), 0, 255).astype(np.uint8)   # toMatrixd_atuc of an image crop
     return uv_f, R_f, r_f, patch_f
+
+
+def make_scene_records(cam, fr, h, visible, seed=0):
+    """A static scene consistent with a prediction: a smooth random image and, per feature, the record
+    Map::initialize_a_features would have stored had the feature been initialised from THIS image at the
+    predicted pixel with the prior's pose (Map.cpp:286-292): uv = round(h), R_wc / r_wc of x_pred, the 41 x 41
+    crop around uv.  pred_patch_fc then warps with a homography close to the identity and the NCC search
+    finds every visible feature.  Returns image (nRows, nCols) uint8, uv_f, R_f, r_f, patch_f."""
+    rng = np.random.default_rng(SEED_BASE + 0x7C3E0000 + seed)
+    nR, nC = int(cam.nRows), int(cam.nCols)
+    base = rng.normal(0.0, 1.0, (nR + 8, nC + 8))
+    k = np.array([1.0, 4.0, 6.0, 4.0, 1.0]); k /= k.sum()
+    for ax in (0, 1):
+        base = sum(np.roll(base, s - 2, axis=ax) * k[s] for s in range(5))
+    base = base[4:-4, 4:-4]
+    image = np.clip(128.0 + 60.0 * base / base.std(), 0, 255).astype(np.uint8)
+    L = fr.L
+    uv_f = np.zeros((L, 2)); R_f = np.zeros((L, 3, 3)); r_f = np.zeros((L, 3)); patch_f = np.zeros((L, 41, 41))
+    Rwc = q2r(fr.x_pred[3:7])
+    padded = np.pad(image, 20, mode="edge").astype(np.float64)
+    for i in range(L):
+        u, v = (h[i] if visible[i] else (nC / 2, nR / 2))
+        u = int(min(max(round(float(u)), 0), nC - 1)); v = int(min(max(round(float(v)), 0), nR - 1))
+        uv_f[i] = (u, v); R_f[i] = Rwc; r_f[i] = fr.x_pred[:3]
+        patch_f[i] = padded[v:v + 41, u:u + 41]                  # rows = image rows around v, columns around u
+    return image, uv_f, R_f, r_f, patch_f

@@ -1,0 +1,244 @@
+"""BASELINE.json configurations at their exact sizes, through the C ABI, against the oracle:
+C2 (100 landmarks / 200 hypotheses), C4 (300 landmarks / 4000 hypotheses scored as 8 slices of
+500, the per-GPU share of the 8-GPU run, gathered, then one consensus + update), and the
+sharded driver (ShardedFrame + HipEngine) on one device.  C3 and C5 live in test_gpu_parity.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from ransac_slam_amd import default_config
+from ransac_slam_amd.sharded import slice_bounds
+from ransac_slam_amd.synth import make_frame
+
+pytestmark = pytest.mark.gpu
+
+X_TOL = 1e-9
+P_TOL = 1e-9
+
+
+def close_x(a, b):
+    return np.max(np.abs(a - b)) <= X_TOL * max(1.0, float(np.max(np.abs(b))))
+
+
+def close_P(a, b):
+    return np.max(np.abs(a - b)) <= P_TOL * float(np.max(np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (the product path has no CPU fallback)")
+    from ransac_slam_amd import api
+    api.lib()
+    return api
+
+
+# --------------------------------------------------------------------------- C2
+@pytest.mark.parametrize("mode", [(1, 1), (0, 1), (0, 0), (1, 0)], ids=lambda m: "compat%d_adaptive%d" % m)
+def test_c2_exact_config(hip, oracle_lib, mode):
+    """BASELINE config C2: make_frame(L=100, H=200, seed=1), the workload `bench.py --workload C2` runs.
+    Reference-structure oracle (dense H_i, dense per-iteration S and K, LU inverses)."""
+    compat, adaptive = mode
+    fr = make_frame(L=100, H=200, seed=1)
+    cfg = default_config(compat=compat, adaptive=adaptive)
+    o = oracle_lib.Oracle(cfg, structure=0)
+    h0, v0, S0 = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    g = hip.RslamHip(cfg)
+    h1, v1, S1 = g.predict(fr.types, fr.x_pred, fr.P_pred)
+    assert np.array_equal(v0, v1)
+    vb = v0.astype(bool)
+    assert np.allclose(h1[vb], h0[vb], rtol=0, atol=1e-9) and np.allclose(S1[vb], S0[vb], rtol=1e-10, atol=1e-12)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z, ic, fr.draws)
+    r1 = g.ransac_update(fr.z, ic, fr.draws)
+    sup0, _, masks0 = o.supports()
+    sup1, masks1 = g.fetch_supports()
+    ne = len(sup0)
+    assert np.array_equal(sup1[:ne], sup0) and np.array_equal(masks1[:ne], masks0)
+    for k in ("best_hyp", "best_support", "hyps_evaluated"):
+        assert r1[k] == r0[k], k
+    assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+    assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+    sm, rm = o.margins()
+    assert sm > 1e-9 and rm > 1e-9
+    # the resident, hipGraph-replayed frame (what the benchmark times) gives the same answer
+    c = hip.RslamHip(cfg)
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+    for _ in range(3):
+        c.step_frame(True)
+    c.sync()
+    r2 = c.fetch_results()
+    assert np.array_equal(r2["li"], r0["li"]) and np.array_equal(r2["hi"], r0["hi"])
+    assert close_x(r2["x_new"], r0["x_new"]) and close_P(r2["P_new"], r0["P_new"])
+    g.close(); c.close()
+
+
+# --------------------------------------------------------------------------- C4
+@pytest.mark.parametrize("compat", [1, 0])
+def test_c4_eight_slices_of_500(hip, oracle_lib, compat):
+    """BASELINE config C4 on one GPU: 300 landmarks, 4000 hypotheses scored in the 8 contiguous slices the
+    8 ranks would own (500 each), written into one gathered support list, then consensus + updates
+    once -- against the oracle's sequential loop over all 4000 (Tracking.cpp:403,507-537)."""
+    import torch
+    H, world = 4000, 8
+    fr = make_frame(L=300, H=H, seed=3)
+    for adaptive in (1, 0):
+        cfg = default_config(compat=compat, adaptive=adaptive)
+        o = oracle_lib.Oracle(cfg, structure=1)
+        _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
+        ic = (fr.ic & v0).astype(np.uint8)
+        r0 = o.ransac_update(fr.z, ic, fr.draws)
+        sup0, _, masks0 = o.supports()
+        c = hip.RslamHip(cfg)
+        c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+        gathered = torch.zeros(H, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        for rank in reversed(range(world)):              # the order of arrival must not matter
+            b, e, chunk = slice_bounds(H, rank, world)
+            assert e - b == 500 and chunk == 500
+            # phase 0 of a rank: predict + score its slice (eager here; every rank's buffer is the gathered one)
+            c.step_phase(0, b, e, gathered.data_ptr(), False)
+        c.step_phase(1, 0, H, gathered.data_ptr(), False)
+        c.sync()
+        r1 = c.fetch_results()
+        sup1, masks1 = c.fetch_supports()
+        ne = len(sup0)                                   # adaptive: the oracle stops early; the device scores everything
+        assert np.array_equal(gathered.cpu().numpy()[:ne], sup0)
+        assert np.array_equal(masks1[:ne], masks0)
+        for k in ("best_hyp", "best_support", "hyps_evaluated"):
+            assert r1[k] == r0[k], (k, r1[k], r0[k])
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+        assert min(o.margins()) > 1e-9
+        # and the graph-replayed two-phase frame of one rank that owns everything
+        for _ in range(2):
+            c.step_phase(0, 0, H, gathered.data_ptr(), True)
+            c.step_phase(1, 0, H, gathered.data_ptr(), True)
+        c.sync()
+        r2 = c.fetch_results()
+        assert np.array_equal(r2["li"], r1["li"]) and np.array_equal(r2["hi"], r1["hi"])
+        assert np.array_equal(r2["x_new"], r1["x_new"]) and np.array_equal(r2["P_new"], r1["P_new"])
+        c.close()
+
+
+# --------------------------------------------------------------------------- sharded driver with the product engine
+def test_sharded_frame_hip_engine_world1(hip):
+    """ShardedFrame + HipEngine on the default stream: the engine must move to a stream of its own
+    (handle 0 would mean "the context's private stream", unordered with a collective)."""
+    import torch
+    from ransac_slam_amd.sharded import HipEngine, ShardedFrame
+    fr = make_frame(L=60, H=200, seed=303)
+    cfg = default_config(compat=0, adaptive=1)
+    ref = hip.RslamHip(cfg)
+    ref.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    ref.step_frame(False); ref.sync()
+    full = ref.fetch_results()
+    ref.close()
+    c = hip.RslamHip(cfg)
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    assert torch.cuda.current_stream().cuda_stream == 0
+    eng = HipEngine(c, 0, use_graph=True)
+    assert eng.stream.cuda_stream != 0
+    sf = ShardedFrame(eng)
+    for _ in range(3):
+        sf.step()
+    c.sync()
+    part = c.fetch_results()
+    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+        assert part[k] == full[k]
+    assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+    c.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _two_rank_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from ransac_slam_amd import api
+    from ransac_slam_amd.sharded import HipEngine, ShardedFrame
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fr = make_frame(L=60, H=257, seed=302)
+        c = api.RslamHip(default_config(compat=0, adaptive=1))
+        c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+        eng = HipEngine(c, 0, use_graph=True)
+        sf = ShardedFrame(eng)
+        for _ in range(3):
+            sf.step()
+        c.sync()
+        r = c.fetch_results()
+        q.put((rank, {k: int(r[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")},
+               r["x_new"].tobytes(), r["P_new"].tobytes(), sf.all[:257].cpu().tolist()))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_frame_hip_engine_two_ranks_one_device(hip):
+    """world_size 2 on ONE device (gloo moves the supports; on a node it is RCCL): both ranks must end
+    with the single-process frame, bit for bit."""
+    import torch.multiprocessing as mp
+    fr = make_frame(L=60, H=257, seed=302)
+    ref = hip.RslamHip(default_config(compat=0, adaptive=1))
+    ref.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    ref.step_frame(False); ref.sync()
+    full = ref.fetch_results()
+    sup_full, _ = ref.fetch_supports()
+    ref.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        item = q.get(timeout=480)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        scal, xb, Pb, gathered = got[rank]
+        for k, v in scal.items():
+            assert v == full[k], (rank, k)
+        assert gathered == sup_full.tolist()
+        assert xb == full["x_new"].tobytes() and Pb == full["P_new"].tobytes()
+
+
+# --------------------------------------------------------------------------- unsynced pipeline
+def test_unsynced_frame_into_ekf_prediction(hip, oracle_lib):
+    """A low-inlier frame (synced) sizes the factor sweep small; the next, high-inlier frame runs through
+    step_frame and straight into rslam_ekf_prediction with no rslam_sync in between: the prior that comes out
+    must be the oracle's (a sweep that was enqueued too short has to be noticed and re-run before its
+    posterior is propagated)."""
+    cfg = default_config(compat=0, adaptive=1)
+    lo = make_frame(L=150, H=120, seed=311, frac_outlier=1.0)
+    hi_fr = make_frame(L=150, H=120, seed=313, frac_outlier=0.0)
+    g = hip.RslamHip(cfg)
+    for _ in range(3):                                  # caps shrink at syncs
+        g.load_frame(lo.types, lo.x_pred, lo.P_pred, lo.z, lo.ic, lo.draws)
+        g.step_frame(True); g.sync()
+    o = oracle_lib.Oracle(cfg, structure=1)
+    _, v0, _ = o.predict(hi_fr.types, hi_fr.x_pred, hi_fr.P_pred)
+    ic = (hi_fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(hi_fr.z, ic, hi_fr.draws)
+    assert int(r0["li"].sum()) > 60
+    xp0, Pp0 = oracle_lib.ekf_prediction(r0["x_new"], r0["P_new"], 1.0, 0.007, 0.007)
+    g.load_frame(hi_fr.types, hi_fr.x_pred, hi_fr.P_pred, hi_fr.z, ic, hi_fr.draws)
+    g.step_frame(True)                                  # no sync
+    g.ekf_prediction(1.0, 0.007, 0.007)
+    xp1, Pp1 = g.fetch_prior()
+    assert close_x(xp1, xp0) and close_P(Pp1, Pp0)
+    g.close()
