@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "tile_gemm.h"
 #include <vector>
+#include <type_traits>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -478,9 +479,11 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
                       int slot_k, int slot_nblk, const double* __restrict__ H13, const int32_t* __restrict__ off,
                       const uint8_t* __restrict__ type,
                       const double* __restrict__ z, const double* __restrict__ h, double* __restrict__ A,
-                      const double* __restrict__ Wsrc /* nullable */, const int32_t* __restrict__ rank_of)
+                      const double* __restrict__ Wsrc /* nullable */, const int32_t* __restrict__ rank_of,
+                      int32_t* __restrict__ sweep_flags /* nullable */)
 {
     const int c = blockIdx.x;
+    if (sweep_flags && c == 0 && threadIdx.x < SWEEP_FLAG_INTS) sweep_flags[threadIdx.x] = 0;   // hand-over flags of the persistent sweep
     if (c >= 64 * sel[slot_nblk]) return;
     const int r = 2 * sel[slot_k];
     double* col = A + (long)c * d.ldA;
@@ -517,10 +520,11 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
 void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* list, const int32_t* sel,
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
                            const uint8_t* type, const double* z, const double* h, double* A,
-                           const double* Wsrc, const int32_t* rank_of)
+                           const double* Wsrc, const int32_t* rank_of, int32_t* sweep_flags)
 {
     if (d.RP <= 0) return;
-    prepare_system_kernel<<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A, Wsrc, rank_of);
+    prepare_system_kernel<<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A, Wsrc, rank_of,
+                                                         sweep_flags);
 }
 
 // ---------------------------------------------------------------------------
@@ -648,7 +652,8 @@ __device__ __forceinline__ double rsqrt_chain(double d)
 __device__ constexpr int cd_tr(int idx) { return idx < 1 ? 0 : idx < 3 ? 1 : idx < 6 ? 2 : 3; }
 __device__ constexpr int cd_tc(int idx) { return idx - (idx < 1 ? 0 : idx < 3 ? 1 : idx < 6 ? 3 : 6); }
 
-// Panel wave: the pivot chain.
+// Panel wave: the pivot chain.  KEEP_L = false: L itself is not collected (persistent sweep: nobody reads it).
+template <bool KEEP_L = true>
 __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
 {
     const int l = threadIdx.x & 63;
@@ -717,8 +722,10 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
             // diagonal of L is never read
             double* Xc = sh.Xs[q];
             Xc[l] = xp0; Xc[64 + l] = xp1; Xc[128 + l] = xp2; Xc[192 + l] = xp3;
-            sh.Lf[(p0 + 0) * CD_LD + l] = xp0; sh.Lf[(p0 + 1) * CD_LD + l] = xp1;
-            sh.Lf[(p0 + 2) * CD_LD + l] = xp2; sh.Lf[(p0 + 3) * CD_LD + l] = xp3;
+            if (KEEP_L) {
+                sh.Lf[(p0 + 0) * CD_LD + l] = xp0; sh.Lf[(p0 + 1) * CD_LD + l] = xp1;
+                sh.Lf[(p0 + 2) * CD_LD + l] = xp2; sh.Lf[(p0 + 3) * CD_LD + l] = xp3;
+            }
             if (l == 0) { double* R = sh.Rs[q & 1]; R[0] = r0; R[1] = r1; R[2] = r2; R[3] = r3; }
             CD_STAMP(sd);
             cd_post(sh, 0, s + 1);
@@ -729,10 +736,14 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
     }
 }
 
-// Inverse wave: pivot rows of the running inverse, one block behind the panel wave.
-__device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
+// Inverse wave: pivot rows of the running inverse, one block behind the panel wave.  Returns (CHECK only) whether a
+// pivot was not a positive finite number: where L is not collected this wave, which is off the chain, looks at the
+// reciprocal square roots the panel wave publishes.
+template <bool CHECK = false>
+__device__ __forceinline__ bool cd_inverse_wave(CdShared& sh, int n_piv4)
 {
     const int l = threadIdx.x & 63;
+    bool bad = false;
     double mp0 = 0.0, mp1 = 0.0, mp2 = 0.0, mp3 = 0.0;     // own column of Ms of the previous block
 #pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
@@ -740,7 +751,7 @@ __device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
         for (int q = 0; q < 4; ++q) {
             const int s = 4 * sb + q;                     // block
             const int p0 = 16 * sb + 4 * q;
-            if (s >= n_piv4) return;
+            if (s >= n_piv4) return bad;
             cd_wait<1>(sh, s + 1, 0, 0, s + 1);           // panel s (L4, reciprocals); strip of block s (M waves, iteration s)
             const double* Mc = sh.Mst[q & 1];
             const double* Xp = sh.Xs[(q + 3) & 3];        // panel s-1
@@ -756,6 +767,7 @@ __device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
             const double l21 = Xc[64 + p0 + 2], l31 = Xc[64 + p0 + 3], l32 = Xc[128 + p0 + 3];
             const double q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
             __builtin_amdgcn_sched_barrier(0);           // every LDS read of the block is in flight before the arithmetic starts
+            if (CHECK) bad = bad || !(q0 > 1e-300 && q0 < 1e300 && q1 > 1e-300 && q1 < 1e300 && q2 > 1e-300 && q2 < 1e300 && q3 > 1e-300 && q3 < 1e300);
             {   // strip column l: M(p0+k, l) -= sum_j X_prev(p0+k, j) Ms_prev(j, l)
                 const double ms[4] = {mp0, mp1, mp2, mp3};
 #pragma unroll
@@ -777,6 +789,7 @@ __device__ __forceinline__ void cd_inverse_wave(CdShared& sh, int n_piv4)
             cd_post(sh, 1, s + 1);
         }
     }
+    return bad;
 }
 
 // T wave B: tiles B, B + CD_TW, ... (< 10) of the trailing matrix.
@@ -949,7 +962,7 @@ __device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict_
             }
         }
     }
-    if (pending == 2) {
+    if (pending >= 2) {
         const double* Ag = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
         const double* Lg = Linv + (long)(step - 1) * 64 * 64;
         const int row = t & 63, g = t >> 6;
@@ -957,15 +970,22 @@ __device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict_
         for (int q = 0; q < 64 / (CD_THREADS / 64); ++q) {
             const int m = g + (CD_THREADS / 64) * q;
             pre.a[q] = Ag[row + (long)m * ldA];
-            pre.l[q] = Lg[row + 64 * m];
+            if (pending == 2) pre.l[q] = Lg[row + 64 * m];      // pending 3: L^-1 of the previous block is still in LDS
         }
     }
 }
 
+// pending: 0 nothing; 1 lookahead (the panel X = A(k,k-1) is in global memory, T -= X X^T is applied here);
+//          2 single-launch block step (X is formed here from A(k,k-1) and L^-1(k-1), both preloaded from global memory);
+//          3 persistent sweep (as 2, but L^-1(k-1) is what this workgroup left in sh.Mf and A(k,k-1) is staged in
+//            `aop_ext`, a 64 x CD_OPLD buffer behind the CdShared; L is not written back: nobody reads it).
 __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
                                                 const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
-                                                int32_t* __restrict__ status, int pending, const CdPre& pre)
+                                                int32_t* __restrict__ status, int pending, const CdPre& pre,
+                                                double* aop_ext = nullptr, unsigned long long* stamp = nullptr)
 {
+#define CD_WSTAMP(slot) do { if (stamp && threadIdx.x == 0) stamp[slot] = wall_clock64(); } while (0)
+    CD_WSTAMP(1);
     // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
     // chain stops after the last real row, L and L^-1 are the identity there
     const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
@@ -976,18 +996,19 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     double* Lout = Linv + (long)step * 64 * 64;
     CD_STAMP(pr0);
     const d4 (&tacc)[CD_TT] = pre.tacc;
-    if (pending == 2) {
+    if (pending >= 2) {
         // Single-launch block step: the panel row of THIS block for the previous column, X = A(k,k-1) Linv(k-1)^T,
         // is formed here (nobody else needs it: the tile workgroups of the same launch recompute the S-row panels
         // they use).  Operands staged behind Lf, over members that are initialised afterwards.
-        double* Aop = sh.Mf;                         // [m][CD_OPLD] : A(k,k-1)(row, m)
-        double* Lop = sh.Mf + 64 * CD_OPLD;          // [m][CD_OPLD] : Linv(k-1)(c, m)
+        double* Aop = (pending == 3) ? aop_ext : sh.Mf;                     // [m][CD_OPLD] : A(k,k-1)(row, m)
+        const double* Lop = (pending == 3) ? sh.Mf : sh.Mf + 64 * CD_OPLD;  // [m][ldl]     : Linv(k-1)(c, m)
+        const int ldl = (pending == 3) ? CD_LD : CD_OPLD;                   // Mf[m * CD_LD + c] = Linv(c, m): the same image
         const int row = t & 63, g = t >> 6;
 #pragma unroll
         for (int q = 0; q < 64 / (CD_THREADS / 64); ++q) {
             const int m = g + (CD_THREADS / 64) * q;
             Aop[m * CD_OPLD + row] = pre.a[q];
-            Lop[m * CD_OPLD + row] = pre.l[q];
+            if (pending == 2) sh.Mf[64 * CD_OPLD + m * CD_OPLD + row] = pre.l[q];
         }
         __syncthreads();
         CD_STAMP(pr1);
@@ -1003,7 +1024,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
                 for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[(kk + lr) * CD_OPLD + 16 * tr + lc],
-                                                               Lop[(kk + lr) * CD_OPLD + 16 * tc + lc], acc, 0, 0, 0);
+                                                               Lop[(kk + lr) * ldl + 16 * tc + lc], acc, 0, 0, 0);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) sh.Lf[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
             }
@@ -1011,6 +1032,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         __syncthreads();
         CD_STAMP(pr2);
         CD_ACC_T(9, pr1, pr2, 0);
+        CD_WSTAMP(2);
     }
     CD_STAMP(pr3);
     {
@@ -1036,8 +1058,10 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         __syncthreads();                                             // (C)
         CD_STAMP(pr4);
         CD_ACC_T(10, pr3, pr4, 0);
+        CD_WSTAMP(3);
         if (wave == 0) cd_panel_wave(sh, n_piv4);
-        else cd_inverse_wave(sh, n_piv4);
+        else (void)cd_inverse_wave(sh, n_piv4);
+        CD_WSTAMP(4);
         CD_STAMP(pr5);
         CD_ACC_T(11, pr4, pr5, 0);
     } else {
@@ -1051,6 +1075,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         }
     }
     __syncthreads();
+    CD_WSTAMP(5);
     bool bad = false;
     {
         const int i = t & 63, g = t >> 6;
@@ -1061,7 +1086,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             const double mv = (i >= done) ? ((i == c) ? 1.0 : 0.0) : sh.Mf[c * CD_LD + i];
             if (i == c && !(lv > 0.0 && lv < 1.0e300)) bad = true;      // a non-positive pivot turns the diagonal into NaN / 0 / inf
             Lout[i + 64 * c] = (i >= c) ? mv : 0.0;
-            if (i >= c) tile[i + (long)c * ldA] = lv;
+            if (i >= c && pending != 3) tile[i + (long)c * ldA] = lv;
         }
     }
     CD_STAMP(pr6);
@@ -1069,6 +1094,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     if (t == 0) { CD_ACC_T(13, pr0, pr0 + 1, 0); }
     if (bad) atomicMin(status, -6);                              // RSLAM_ERR_NOT_SPD
     if (t == 0 && sh.timeout) atomicMin(status, -3);             // RSLAM_ERR_HIP: hand-over protocol broke (never expected)
+#undef CD_WSTAMP
 }
 
 __global__ void __launch_bounds__(CD_THREADS)
@@ -1265,6 +1291,561 @@ trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
     trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
 }
 
+// ---------------------------------------------------------------------------
+// K8, persistent form: the whole factor sweep of one update in ONE launch (systems whose workgroups are all
+// resident at once; launch_factor_sweep decides).  Launch boundaries are replaced by flags in global memory:
+//   workgroup 0        the pivot chain: diagonal blocks 0, 1, ... back to back (cd_chain_persistent).
+//   strip workgroups   one per 16-row strip of the stacked matrix [S; P H^T; nu^T].  A strip keeps its rows of ALL
+//                      column blocks in MFMA accumulators for the whole sweep (16 x 64 nblk doubles over 8 waves):
+//                      the system is read once and Y written once.  Step k (right-looking), as soon as L^-1(k) is out:
+//                      X = strip(:,k) L^-T(k) (final: stored), then strip(:,j) -= X L(j,k)^T for j > k, with the
+//                      panel blocks L(j,k) that the strips of the S rows j publish (buffer Ypanel + counter
+//                      panel_cnt[k]).  The strips of S row block b hand the tiles (b,b-1), (b,b) with every update
+//                      but the last to the chain (in place + counter row_ready[b]) while the chain factors block b-1.
+// Products are computed transposed (D = L_tile X^T) so that accumulator loads/stores and the operand fetch of the
+// panel tiles are 128-byte row segments of the column-major matrix.
+// Memory protocol: an MI355X has eight L2 caches (one per XCD) that are not coherent with each other inside a
+// kernel.  Agent-scope fences would make them so by writing back / invalidating a whole L2 on every hand-over
+// (buffer_wbl2 / buffer_inv sc1: measured 3-5 us per fence while 160 workgroups stream their operands).  Instead
+// every datum that crosses workgroups is written and read with agent-scope relaxed atomics -- global_store /
+// global_load ... sc1, which go to the memory side -- the producer waits for its stores (s_waitcnt vmcnt(0)) before
+// the flag, the consumer polls the flag with the same kind of load.  Data read from the previous kernel (the
+// prepared system) and results read by the next kernel (Y) use ordinary accesses.
+// Forward progress: a workgroup only waits for workgroup 0 and for strips of S rows, which have lower block indices
+// and are dispatched first; the host only takes this path when the whole grid is resident at once.  Every wait is
+// bounded (status -3) so that a scheduling surprise ends in an error code, never in a hung queue.
+// ---------------------------------------------------------------------------
+// optional time stamps (100 MHz wall clock) of the persistent sweep: dbg[who][block/step][slot], see scripts/sweep_stamps.py
+constexpr int SWD_WHO = 5, SWD_K = 16, SWD_SLOT = 8;
+__device__ __forceinline__ void sw_stamp(unsigned long long* dbg, int who, int k, int slot, int tid = 0)
+{
+    if (dbg && (int)threadIdx.x == tid && k < SWD_K) dbg[(who * SWD_K + k) * SWD_SLOT + slot] = wall_clock64();
+}
+
+constexpr int SW_MAX_BLOCKS = 32;
+struct SweepFlags {
+    int32_t linv_ready;                 // diagonal blocks whose L^-1 is published
+    int32_t xrow_ready;                 // k: the chain has published its panel blocks L(1,0) .. L(k,k-1)
+    int32_t pad[14];
+    int32_t panel_cnt[SW_MAX_BLOCKS];   // [k]: S strips that have published their rows of panel k (row blocks k+2 ..)
+    int32_t row_ready[SW_MAX_BLOCKS];   // [b]: strips of S row block b that have handed tiles (b,b-1), (b,b) over
+    int32_t row_cnt[SW_MAX_BLOCKS];     // [b]: panel rows published by the strips of S row block b, all steps (4 per step)
+};
+static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag block size");
+constexpr int SW_SPIN_LIMIT = 1 << 18;       // ~0.2 s; the longest legitimate wait is one diagonal block (~15 us)
+
+// data that crosses workgroups inside the launch (see "Memory protocol" above)
+__device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_flag(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// All threads of the workgroup.  Returns true when *flag >= need; false when the spin bound was hit (status -3) or an
+// earlier wait of this workgroup had failed (*abort, in LDS): the caller then leaves at once, so that a broken
+// hand-over costs one bound per workgroup, not one per wait.
+// Timeouts are reported as status -(30 + code) (the host maps everything <= -30 to RSLAM_ERR_HIP and keeps the raw value
+// for diagnosis): 1 L^-1 flag, 2 chain's panel row, 3 sibling strips, 4 all S strips, 5 hand-over (chain), 6 LDS pipeline
+// of the chain workgroup.
+__device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* status, int* abort, int code = 0)
+{
+    if (threadIdx.x == 0) {
+        // two polls in flight, half a memory latency apart: the flag is seen ~half a latency earlier than with one
+        int spins = 0;
+        int a = ld_flag(flag);
+        while (true) {
+            __builtin_amdgcn_s_sleep(4);
+            int b = ld_flag(flag);
+            if (a >= need) break;
+            __builtin_amdgcn_s_sleep(4);
+            a = ld_flag(flag);
+            if (b >= need) break;
+            if (++spins > SW_SPIN_LIMIT) { atomicMin(status, -(30 + code)); *abort = 1; break; }
+        }
+    }
+    __syncthreads();
+    return *abort == 0;
+}
+
+// all threads: the coherent stores of this workgroup have reached memory, then *flag += 1
+__device__ __forceinline__ void sw_post_add(int32_t* flag)
+{
+    wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// compile-time loop: the accumulator array of a strip must never be indexed dynamically (it would move to scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Eight waves: wave = 4 g + w.  Group g owns the column blocks j = 2 jj + g, wave w the columns 16 w .. 16 w + 15 of each.
+template <int NJ>
+__device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, int nblk, int strip,
+                                            const double* Linv, double* Ypanel, SweepFlags* fl, int32_t* status, double* lds,
+                                            unsigned long long* dbg)
+{
+    constexpr int NH = (NJ + 1) / 2;                        // column blocks per group
+    const int b = strip >> 2;                               // 64-row block of the strip
+    int who = -1;
+    if (dbg) who = (strip == 8) ? 1 : (strip == 4 * (nblk - 1)) ? 2 : (strip == 4 * rp_blocks) ? 3 : (strip == (int)(ldA / 16) - 4) ? 4 : -1;
+    if (who < 0) dbg = nullptr;
+    const bool is_s = b < rp_blocks;
+    // padding rows of S; row block 0 is the first diagonal block only; row block 1 goes to the chain as it is prepared
+    if (is_s && (b >= nblk || b <= 1)) return;
+    if (b == (int)(ldA / 64) - 1 && (strip & 3) != 0) return;   // below nu^T there is only zero padding
+    const int ncols = is_s ? b + 1 : nblk;                  // column blocks held
+    // steps k = 0 .. nsteps - 1, each followed by updates except the last of a P H^T strip.  S row block b stops after
+    // step b-2: its step b-1 -- the panel block L(b,b-1) and the update of tile (b,b) -- is the chain's own prologue of
+    // diagonal block b, and the chain publishes that panel block itself (flag xrow_ready).
+    const int nsteps = is_s ? b - 1 : nblk;
+    const int nupd = is_s ? b - 1 : nblk - 1;
+    const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6), g = wv >> 2, w = wv & 3;
+    const int l = t & 63, ln = l & 15, lq = l >> 4;
+    double* Sk = lds;                  // [64][16]: the strip's column block k before the solve (B operand of the X product)
+    double* Xs = lds + 64 * 16;        // [64][16]: X, the solved column block (B operand of the updates)
+    int* abort = reinterpret_cast<int*>(lds + 2 * 64 * 16);
+    bool alive = true;
+    if (t == 0) *abort = 0;            // (the first wait has a barrier before anybody reads it)
+    // acc[jj][reg] of lane (ln, lq) = strip(ln, 64 (2 jj + g) + 16 w + lq + 4 reg)
+    double* base = A + 16L * strip + ln + (64L * g + 16L * w + lq) * ldA;
+    d4 acc[NH];
+    static_for<0, NH>([&](auto JJ) {
+        constexpr int jj = decltype(JJ)::value;
+        acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (2 * jj + g < ncols) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[jj][reg] = base[(128L * jj + 4 * reg) * ldA];
+        }
+    });
+    static_for<0, NJ>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if (alive && k < nsteps) { sw_stamp(dbg, who, k, 0); alive = sw_wait(&fl->linv_ready, k + 1, status, abort, 1); sw_stamp(dbg, who, k, 1); }
+        if (alive && k < nsteps) {
+            const bool mine = (g == (k & 1));                // this group holds column block k
+            const double* Lk = Linv + 64L * 64 * k;
+            // L^-1 rows 16 w .. 16 w + 15 are zero right of column 16 w + 15: 4 (w + 1) MFMA steps
+            double la[16];
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) la[q] = (q < 4 * (w + 1)) ? ld_coh(Lk + (16 * w + ln) + 64 * (4 * q + lq)) : 0.0;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Sk[(16 * w + lq + 4 * reg) * 16 + ln] = acc[k >> 1][reg];
+            }
+            __syncthreads();
+            if (mine) {
+                d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q < 4 * (w + 1)) x = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], Sk[(4 * q + lq) * 16 + ln], x, 0, 0, 0);
+                // x[reg] = X(ln, 16 w + lq + 4 reg): final.  P H^T / nu rows: Y in place; S rows: a panel block for the others
+                double* dst = (is_s ? Ypanel : A) + 16L * strip + ln + (64L * k + 16 * w + lq) * ldA;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (is_s) st_coh(dst + (4L * reg) * ldA, x[reg]); else dst[(4L * reg) * ldA] = x[reg];
+                    Xs[(16 * w + lq + 4 * reg) * 16 + ln] = x[reg];
+                }
+            }
+            if (is_s) {
+                wait_stores();
+                __syncthreads();
+                if (t == 0) {
+                    __hip_atomic_fetch_add(&fl->row_cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&fl->panel_cnt[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else __syncthreads();
+            sw_stamp(dbg, who, k, 2);
+            if (k < nupd) {
+                double xb[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xb[q] = Xs[(4 * q + lq) * 16 + ln];
+                // panel blocks L(j,k): j = k+1 from the chain, j >= k+2 from the strips of S row block j.  The step that
+                // ends with the hand-over to the chain (S rows, k = b-2) only needs j = b-1 = k+1 and j = b, its own
+                // row block: it waits for its three siblings, not for every S strip
+                if (alive) alive = sw_wait(&fl->xrow_ready, k + 1, status, abort, 2);
+                if (alive) {
+                    if (is_s && k == b - 2) alive = sw_wait(&fl->row_cnt[b], 4 * (k + 1), status, abort, 3);
+                    else if (k + 2 < nblk) alive = sw_wait(&fl->panel_cnt[k], 4 * (nblk - 2 - k), status, abort, 4);
+                }
+                sw_stamp(dbg, who, k, 3);
+                // column blocks j = 2 jj + g, k < j < ncols: a contiguous jj range whose lower end is known at compile
+                // time per group; the operand rows of tile jj + 1 are in flight under the MFMAs of tile jj
+                auto updates = [&](auto G) {
+                    constexpr int gg = decltype(G)::value;
+                    constexpr int lo = (k + 2 - gg) / 2;             // smallest jj with 2 jj + gg > k
+                    const int hi = (ncols - gg + 1) / 2;             // jj < hi  <=>  2 jj + gg < ncols
+                    const double* Lp = Ypanel + 64L * gg + (16 * w + ln) + (64L * k + lq) * ldA;   // + 128 jj: rows 16 w.. of panel block (j,k)
+                    double a[2][16];
+                    if (alive && lo < hi && lo < NH) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) a[0][q] = ld_coh(Lp + 128L * lo + (4L * q) * ldA);
+                    }
+                    static_for<lo, NH>([&](auto JJ) {
+                        constexpr int jj = decltype(JJ)::value;
+                        constexpr int cur = (jj - lo) & 1;
+                        if (alive && jj < hi) {
+                            if (jj + 1 < hi && jj + 1 < NH) {
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) a[cur ^ 1][q] = ld_coh(Lp + 128L * (jj + 1) + (4L * q) * ldA);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[cur][q], xb[q], acc[jj], 0, 0, 0);
+                        }
+                    });
+                };
+                if (g == 0) updates(std::integral_constant<int, 0>{}); else updates(std::integral_constant<int, 1>{});
+                sw_stamp(dbg, who, k, 4);
+                if (alive && is_s && k == b - 2) {
+                    // the chain factors block b after block b-1: hand tiles (b,b-1), (b,b) over, updates 0 .. b-2 applied
+                    static_for<(k + 1) / 2, (k / 2 + 2 < NH ? k / 2 + 2 : NH)>([&](auto JJ) {
+                        constexpr int jj = decltype(JJ)::value;
+                        const int j = 2 * jj + g;
+                        if (j == k + 1 || j == k + 2) {
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) st_coh(base + (128L * jj + 4 * reg) * ldA, acc[jj][reg]);
+                        }
+                    });
+                    sw_post_add(&fl->row_ready[b]);
+                    sw_stamp(dbg, who, k, 5);
+                }
+            }
+        }
+    });
+}
+
+// ---- the chain workgroup of the persistent sweep ------------------------------------------------------------------
+// Per diagonal block k the serial path is: [chain of block k-1 ends: L^-1(k-1) complete in LDS] -> X = A(k,k-1) L^-T(k-1)
+// (8 waves, MFMA) -> the update T(k,k) -= X X^T of the FIRST tile column only -> strip of the first four pivots -> chain.
+// Everything else is off that path:
+//   * the inputs of block k -- tiles (k,k-1), (k,k) as the strips of row block k handed them over -- are fetched into
+//     LDS by the T waves DURING the chain of block k-1: a flag load, and two iterations later the data loads, are
+//     issued between pivot steps and consumed iterations later, so that no wave on the pipeline ever waits for memory
+//     (if the hand-over comes too late, the fetch happens at the top of the block and its latency is exposed);
+//   * the tile columns 1..3 of T -= X X^T are applied by the T waves during the first pivot steps (updates commute;
+//     tile column c is first read at pivot 16 c);
+//   * L^-1(k-1) is written to global memory right after the chain ends and its flag goes out after the X product;
+//   * L itself is not kept: nobody reads it.
+constexpr int CDP_AOP_DOUBLES = 64 * CD_OPLD;          // A(k,k-1): [m][CD_OPLD]
+constexpr int CDP_TPRE_DOUBLES = 40 * 64;              // tile (k,k): lower 16 x 16 tiles in accumulator layout [(idx, reg)][lane]
+constexpr size_t CDP_OFF_AOP = (sizeof(CdShared) + 15) / 16 * 2;     // in doubles
+constexpr size_t SWP_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
+
+struct CdpNext {                 // what a T wave fetches for the next block
+    const double* a_src;         // A(k+1,k) + lane (row)
+    const double* tile;          // tile (k+1,k+1)
+    long ldA;
+    const int32_t* flag;         // row_ready[k+1], nullptr = the prepared system (always there)
+    double* Aop; double* Tpre;
+};
+
+// chunk Q (0..3) of T wave B's share: columns B + 4 (4 Q + i), i < 4, of A(k+1,k) and 3/3/2/2 (tile, register) pairs of
+// tile (k+1,k+1).  Small chunks: what a T wave does between two pivot steps must stay well below one step of the chain.
+constexpr __device__ int cdp_t0(int q) { return q < 2 ? 3 * q : 6 + 2 * (q - 2); }      // first pair of chunk q: 0, 3, 6, 8 (, 10)
+
+template <int B, int Q>
+__device__ __forceinline__ void cdp_issue(const CdpNext& nx, double (&pf)[26])
+{
+    const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;     // (the lane offsets are loop invariant: the compiler keeps them)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[4 * Q + i] = ld_coh(nx.a_src + (long)(B + 4 * (4 * Q + i)) * nx.ldA);
+#pragma unroll
+    for (int i = cdp_t0(Q); i < cdp_t0(Q + 1); ++i) {
+        const int p = B + 4 * i, idx = p >> 2, reg = p & 3;
+        const int row = 16 * cd_tr(idx) + lr + 4 * reg, col = 16 * cd_tc(idx) + lc;
+        pf[16 + i] = ld_coh(nx.tile + ((row >= col) ? row + (long)col * nx.ldA : col + (long)row * nx.ldA));   // lower triangle is authoritative
+    }
+}
+
+template <int B, int Q>
+__device__ __forceinline__ void cdp_store(const CdpNext& nx, const double (&pf)[26])
+{
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nx.Aop[(B + 4 * (4 * Q + i)) * CD_OPLD + l] = pf[4 * Q + i];
+#pragma unroll
+    for (int i = cdp_t0(Q); i < cdp_t0(Q + 1); ++i) nx.Tpre[(B + 4 * i) * 64 + l] = pf[16 + i];
+}
+
+// q is a constant once the pivot-step loop is unrolled: the switches fold
+template <int B>
+__device__ __forceinline__ void cdp_issue_q(int q, const CdpNext& nx, double (&pf)[26])
+{
+    switch (q) { case 0: cdp_issue<B, 0>(nx, pf); break; case 1: cdp_issue<B, 1>(nx, pf); break;
+                 case 2: cdp_issue<B, 2>(nx, pf); break; default: cdp_issue<B, 3>(nx, pf); break; }
+}
+template <int B>
+__device__ __forceinline__ void cdp_store_q(int q, const CdpNext& nx, const double (&pf)[26])
+{
+    switch (q) { case 0: cdp_store<B, 0>(nx, pf); break; case 1: cdp_store<B, 1>(nx, pf); break;
+                 case 2: cdp_store<B, 2>(nx, pf); break; default: cdp_store<B, 3>(nx, pf); break; }
+}
+
+// Top of a block: make this wave's share of the block's inputs LDS-resident.  st: 3 = it already is (fetched and stored
+// during the previous chain), 4 = the loads were issued late in the previous chain and are in pf, 7 = the hand-over flag
+// was seen too late to issue anything, anything else: poll and fetch now (kernel start, or a hand-over that came after
+// the chain had ended: the latency is exposed).
+template <int B>
+__device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, double (&pf)[26], int st)
+{
+    if (st == 3) return;
+    if (st != 4) {
+        if (nx.flag && st != 7) {
+            int spins = 0;
+            while (ld_flag(nx.flag) < 4) {
+                if (++spins > SW_SPIN_LIMIT) { sh.timeout = 5; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        cdp_issue<B, 0>(nx, pf); cdp_issue<B, 1>(nx, pf); cdp_issue<B, 2>(nx, pf); cdp_issue<B, 3>(nx, pf);
+    }
+    cdp_store<B, 0>(nx, pf); cdp_store<B, 1>(nx, pf); cdp_store<B, 2>(nx, pf); cdp_store<B, 3>(nx, pf);
+}
+
+// T wave B of the persistent chain.  Returns the state of the fetch of the next block's inputs (see cdp_finish).
+template <int B>
+__device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending, const double* Xb, const double* Tpre,
+                                          const CdpNext& nx, bool want_next, double (&pf)[26], unsigned long long* stamp, int exp_mask)
+{
+    const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
+    constexpr int NT = (10 - B + CD_TW - 1) / CD_TW;
+    constexpr int EO = (cd_tc(B) == 0) ? 0 : 1;        // the tile of the first tile column (one per T wave)
+    static_assert(cd_tc(B + CD_TW * EO) == 0, "every T wave owns one tile of tile column 0");
+    d4 acc[NT];
+#pragma unroll
+    for (int o = 0; o < NT; ++o)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[o][reg] = Tpre[((B + CD_TW * o) * 4 + reg) * 64 + l];
+    auto pend = [&](auto O, int k0, int k1) {           // acc[O] -= X(tr,:) X(tc,:)^T over columns k0 .. k1-1
+        constexpr int o = decltype(O)::value;
+        constexpr int tr = cd_tr(B + CD_TW * o), tc = cd_tc(B + CD_TW * o);
+#pragma unroll 8
+        for (int kk = k0; kk < k1; kk += 4)
+            acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lr) * CD_LD + 16 * tr + lc], -Xb[(kk + lr) * CD_LD + 16 * tc + lc], acc[o], 0, 0, 0);
+    };
+    if (pending) pend(std::integral_constant<int, EO>{}, 0, 64);
+    if (pending && (exp_mask & 2)) {                  // measurement: every tile column at once, as the one-launch-per-step kernel does
+        static_for<0, NT>([&](auto O) { if (decltype(O)::value != EO) pend(O, 0, 64); });
+    }
+    // strip of pivot block 0
+    if (lc < 4) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) sh.Tst[0][lc * 64 + 16 * cd_tr(B + CD_TW * EO) + lr + 4 * reg] = acc[EO][reg];
+    }
+    __syncthreads();                     // (C) strips, flags are visible
+    // Fetch of the next block's inputs, one chunk per pivot step: the hand-over flag is read at step 4; if it is up at
+    // step 8 the loads go out during steps 8..11 and land in LDS during steps 12..15 (st 1 -> 2 -> 3), else the flag is
+    // read again and, if up at step 12, the loads go out during steps 12..15 and are stored at the top of the next
+    // block (st 5 -> 4); else the next block fetches them itself.
+    int st = 0, fv = 4;
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;
+            const int p0 = 16 * sb + 4 * q;
+            if (s >= n_piv4) return st;
+            if (s > 0) {
+                cd_wait<1>(sh, s, 0, 0, 0);                  // panel s-1 (which also means the panel wave is done with strip buffer (s+1) & 1)
+                const double* Xp = sh.Xs[(q + 3) & 3];
+                double a[NT], b[NT];
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    a[o] = Xp[lr * 64 + 16 * cd_tr(B + CD_TW * o) + lc];
+                    b[o] = Xp[lr * 64 + 16 * cd_tc(B + CD_TW * o) + lc];
+                }
+#pragma unroll
+                for (int o = 0; o < NT; ++o) acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);   // T -= X X^T
+            }
+            // strip of block s+1 (updates <= s-1 applied)
+            if (p0 + 4 < 64) {
+                const int p1 = p0 + 4, bb = p1 >> 4, o1 = p1 & 15;
+                double* To = sh.Tst[(q + 1) & 1];
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    if (cd_tc(B + CD_TW * o) == bb && lc >= o1 && lc < o1 + 4) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) To[(lc - o1) * 64 + 16 * cd_tr(B + CD_TW * o) + lr + 4 * reg] = acc[o][reg];
+                    }
+                }
+            }
+            cd_post(sh, 2 + B, s + 1);
+            // ---- behind the published strip: work that is not on the chain
+            if (pending && sb == 0 && !(exp_mask & 2)) {
+                // tile columns >= 1 of T -= X X^T: the first other tile during pivot steps 0 and 1 (needed at step 3 at the
+                // earliest), the second during steps 2 and 3 (needed at step 7)
+                constexpr int L1 = (EO == 0) ? 1 : 0, L2 = 2;
+                if (q < 2) { if (L1 < NT) pend(std::integral_constant<int, (L1 < NT ? L1 : 0)>{}, 32 * q, 32 * q + 32); }
+                else { if (L2 < NT && L2 != EO) pend(std::integral_constant<int, (L2 < NT ? L2 : 0)>{}, 32 * (q - 2), 32 * (q - 2) + 32); }
+            }
+            if (want_next) {
+                if (sb == 1 && q == 0) fv = nx.flag ? ld_flag(nx.flag) : 4;     // consumed four steps later: its latency is hidden
+                if (sb == 2) {
+                    if (q == 0 && fv >= 4) { st = 1; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
+                    if (q == 1 && st == 0) fv = ld_flag(nx.flag);            // second look, consumed at step 12
+                    if (st == 1) cdp_issue_q<B>(q, nx, pf);
+                    if (q == 3 && st == 1) st = 2;
+                } else if (sb == 3) {
+                    if (q == 0 && st == 0 && fv >= 4) { st = 5; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
+                    if (q == 1 && st == 0) { fv = ld_flag(nx.flag); st = 6; }     // third look, consumed at the top of the next block
+                    if (st == 2) cdp_store_q<B>(q, nx, pf);
+                    else if (st == 5) cdp_issue_q<B>(q, nx, pf);
+                    if (q == 3) { if (st == 2) { st = 3; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[6] = wall_clock64(); } else if (st == 5) st = 4; }
+                }
+            }
+        }
+    }
+    return (st == 6 && fv >= 4) ? 7 : st;       // 7: not fetched, but the hand-over has been seen: no polling needed
+}
+
+// One wave role of the chain workgroup over all diagonal blocks.  ROLE: 0 panel wave, 1 inverse wave, 2..5 T waves,
+// 6..7 M waves.  Every role runs the same barrier sequence; the block loop is per role so that what a role carries
+// from block to block (the T waves' fetch registers) does not count against the registers of the others.
+template <int ROLE>
+__device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int nblk, int r_total, double* Linv, double* Ypanel,
+                                         SweepFlags* fl, int32_t* status, unsigned long long* dbg, int exp_mask)
+{
+    CdShared& sh = *reinterpret_cast<CdShared*>(lds);
+    double* Aop = lds + CDP_OFF_AOP;
+    double* Tpre = Aop + CDP_AOP_DOUBLES;
+    double* Xb = sh.Lf;                                   // X = A(k,k-1) L^-T(k-1) lives where L would be collected
+    const int t = threadIdx.x;
+    const int row = t & 63;
+    constexpr int g = ROLE;                               // wave index
+    constexpr bool is_t = (ROLE >= 2 && ROLE < 2 + CD_TW);
+    constexpr int TB = is_t ? ROLE - 2 : 0;
+    int fetch_st = 0;                                     // (T waves) state of the fetch of block k's inputs, see cdp_finish
+    double pf[26];
+    bool bad = false;
+#pragma unroll 1
+    for (int k = 0; k < nblk; ++k) {
+        const int r_here = min(64, max(0, r_total - 64 * k));
+        const int n_piv4 = (r_here + 3) >> 2;
+        const bool pending = k > 0;
+        unsigned long long* stamp = (dbg && k < SWD_K) ? dbg + k * SWD_SLOT : nullptr;
+        if (stamp && t == 0) stamp[0] = wall_clock64();
+        if (pending) {
+            // L^-1(k-1), complete in Mf (a full block), to global memory for the strips
+            double* Lout = Linv + (long)(k - 1) * 64 * 64;
+#pragma unroll
+            for (int c = g; c < 64; c += CD_THREADS / 64) st_coh(Lout + row + 64 * c, (row >= c) ? sh.Mf[c * CD_LD + row] : 0.0);
+        }
+        if constexpr (is_t) {
+            CdpNext cur;
+            cur.a_src = A + (long)k * 64 + row + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
+            cur.tile = A + (long)k * 64 + (long)k * 64 * ldA;
+            cur.ldA = ldA; cur.flag = (k >= 2) ? &fl->row_ready[k] : nullptr; cur.Aop = Aop; cur.Tpre = Tpre;
+            cdp_finish<TB>(cur, sh, pf, fetch_st);
+        }
+        __syncthreads();                                  // inputs of block k are in LDS
+        if (stamp && t == 0) stamp[1] = wall_clock64();
+        if (pending) {
+            // X = A(k,k-1) L^-T(k-1): Mf[m * CD_LD + c] = L^-1(c, m) is the B operand image as it stands.  L^-1 is lower
+            // triangular: column tile tc of X only needs m < 16 (tc + 1); waves pair the column tiles {0,3} and {1,2}
+            const int l = t & 63, lr = l >> 4, lc = l & 15;
+            constexpr int tr = ROLE >> 1;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int tc = (ROLE & 1) ? 1 + o : 3 * o;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[(kk + lr) * CD_OPLD + 16 * tr + lc],
+                                                               sh.Mf[(kk + lr) * CD_LD + 16 * tc + lc], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Xb[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
+            }
+            wait_stores();                                // this wave's part of L^-1(k-1) has reached memory
+        }
+        __syncthreads();
+        if (pending && t == 0) __hip_atomic_store(&fl->linv_ready, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stamp && t == 0) stamp[2] = wall_clock64();
+        if (pending && !is_t) {
+            // X is the panel block L(k,k-1): published for the strips by the four waves that are idle while the T waves
+            // apply the first tile column of T -= X X^T (flag xrow_ready after the barrier below)
+            constexpr int slot = ROLE < 2 ? ROLE : ROLE - CD_TW;             // 0..3
+            double* Xout = Ypanel + (long)k * 64 + (long)(k - 1) * 64 * ldA;
+#pragma unroll
+            for (int c = slot; c < 64; c += 4) st_coh(Xout + row + (long)c * ldA, Xb[c * CD_LD + row]);
+            wait_stores();
+        }
+        if (t < 16) sh.flags[t] = 0;
+        if (g < 4) sh.Xs[3][g * 64 + row] = 0.0;                                         // "panel" -1
+        else { sh.Mst[0][(g - 4) * 64 + row] = 0.0; sh.Mst[1][(g - 4) * 64 + row] = 0.0; }
+        if constexpr (ROLE == 0) {
+            __syncthreads();                                         // (C)
+            if (pending && t == 0) __hip_atomic_store(&fl->xrow_ready, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stamp && t == 0) stamp[3] = wall_clock64();
+            cd_panel_wave<false>(sh, n_piv4);
+            if (stamp && t == 0) stamp[4] = wall_clock64();
+        } else if constexpr (ROLE == 1) {
+            __syncthreads();
+            bad = cd_inverse_wave<true>(sh, n_piv4) || bad;
+        } else if constexpr (is_t) {
+            const bool want_next = (k + 1 < nblk) && !(exp_mask & 1);
+            CdpNext nx;
+            nx.a_src = A + (long)(k + 1) * 64 + row + (long)k * 64 * ldA;
+            nx.tile = A + (long)(k + 1) * 64 + (long)(k + 1) * 64 * ldA;
+            nx.ldA = ldA; nx.flag = (k + 1 >= 2) ? &fl->row_ready[k + 1] : nullptr; nx.Aop = Aop; nx.Tpre = Tpre;
+            fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, nx, want_next, pf, stamp, exp_mask);
+        } else {
+            cd_m_wave<ROLE - 2 - CD_TW>(sh, n_piv4, 0);
+        }
+        __syncthreads();                                  // the chain of block k has ended: L^-1(k) is complete in Mf
+        if (stamp && t == 0) stamp[5] = wall_clock64();
+        if (sh.timeout) { if (t == 0) atomicMin(status, sh.timeout == 5 ? -35 : -(36 + 10 * k)); return; }     // hand-over protocol broke (never expected)
+    }
+    if (bad) atomicMin(status, -6);                       // RSLAM_ERR_NOT_SPD
+    {
+        // L^-1 of the last block: identity beyond the rows that exist
+        const int k = nblk - 1;
+        const int done = 4 * ((min(64, max(0, r_total - 64 * k)) + 3) >> 2);
+        double* Lout = Linv + (long)k * 64 * 64;
+        for (int c = g; c < 64; c += CD_THREADS / 64) {
+            const double mv = (row >= done) ? ((row == c) ? 1.0 : 0.0) : sh.Mf[c * CD_LD + row];
+            st_coh(Lout + row + 64 * c, (row >= c) ? mv : 0.0);
+        }
+        wait_stores();
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&fl->linv_ready, nblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long ldA, int nblk, int r_total, double* Linv, double* Ypanel,
+                                                    SweepFlags* fl, int32_t* status, unsigned long long* dbg, int exp_mask)
+{
+    CdShared& sh = *reinterpret_cast<CdShared*>(lds);
+    if (threadIdx.x == 0) sh.timeout = 0;
+    __syncthreads();
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: cdp_role<0>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 1: cdp_role<1>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 2: cdp_role<2>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 3: cdp_role<3>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 4: cdp_role<4>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 5: cdp_role<5>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 6: cdp_role<6>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    default: cdp_role<7>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    }
+}
+
+template <int NJ>
+__global__ void __launch_bounds__(CD_THREADS)
+sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, int slot_nblk, int slot_k, int rp_blocks,
+                        double* Linv, double* Ypanel, int32_t* flags, int32_t* status, unsigned long long* dbg, int exp_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    SweepFlags* fl = reinterpret_cast<SweepFlags*>(flags);
+    int nblk = sel[slot_nblk];
+    if (nblk > rp_blocks) nblk = rp_blocks;
+    if (nblk <= 0) return;
+    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, Linv, Ypanel, fl, status, lds, dbg);
+    else cd_chain_persistent(lds, A, ldA, nblk, 2 * sel[slot_k], Linv, Ypanel, fl, status, dbg, exp_mask);
+}
+
 // dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
 constexpr size_t CD_STAGE_BYTES = sizeof(double) * (64 * CD_LD + 2 * 64 * CD_OPLD);      // Lf + the two staged operands
 constexpr size_t cd_max(size_t a, size_t b) { return a > b ? a : b; }
@@ -1295,7 +1876,43 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
     return 0;
+}
+
+// The persistent sweep needs every workgroup resident at once: one per CU (its dynamic LDS does not leave room for
+// a second), at most 16 column blocks (the accumulators of a strip are a compile-time array).
+// diagnostic time stamps of the persistent sweep (the last launch wins); off unless a buffer is installed
+static unsigned long long* g_sweep_dbg = nullptr;
+int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nullable = only (un)install */, int enable)
+{
+    const size_t bytes = sizeof(unsigned long long) * SWD_WHO * SWD_K * SWD_SLOT;
+    if (enable && !g_sweep_dbg) {
+        if (hipMalloc((void**)&g_sweep_dbg, bytes) != hipSuccess) { g_sweep_dbg = nullptr; return -1; }
+        (void)hipMemset(g_sweep_dbg, 0, bytes);
+    }
+    if (out && g_sweep_dbg) { if (hipMemcpy(out, g_sweep_dbg, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1; (void)hipMemset(g_sweep_dbg, 0, bytes); }
+    if (!enable && g_sweep_dbg) { (void)hipFree(g_sweep_dbg); g_sweep_dbg = nullptr; }
+    return 0;
+}
+
+bool sweep_persistent_eligible(const SystemDims& d)
+{
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
+    static const bool off = getenv("RSLAM_SWEEP_STEPS") != nullptr;       // measurement: the one-launch-per-step sequence
+    if (off || d.RP <= 0) return false;
+    return d.RP / 64 <= 16 && 1 + d.ldA / 16 <= cus;
 }
 
 // One stream: diag(0), then ONE launch per block step (sweep_step_kernel); for large systems (more than 512 tile
@@ -1308,7 +1925,7 @@ int init_kernel_attributes()
 // sequence, A itself for the others.
 double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
                             const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
-                            int32_t* status_sel)
+                            int32_t* status_sel, int32_t* flags)
 {
     const int rp_blocks = d.RP / 64;
     const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
@@ -1316,6 +1933,19 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
     const bool two = (aux != nullptr && ev != nullptr);
     static const bool unfused = getenv("RSLAM_SWEEP_UNFUSED") != nullptr;
+    if (!two && !unfused && flags && sweep_persistent_eligible(d)) {
+        // one launch for the whole sweep, sized for the largest inlier count the frame can have: the launch sequence
+        // never depends on the previous frame (cap_blocks is not used)
+        const dim3 grid(1 + d.ldA / 16), block(CD_THREADS);
+        static const int exp_mask = getenv("RSLAM_SWEEP_EXP") ? atoi(getenv("RSLAM_SWEEP_EXP")) : 0;   // measurement switches
+#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, Linv, Ystore, flags, status_sel, g_sweep_dbg, exp_mask)
+        if (rp_blocks <= 4) SWP_LAUNCH(4);
+        else if (rp_blocks <= 8) SWP_LAUNCH(8);
+        else if (rp_blocks <= 12) SWP_LAUNCH(12);
+        else SWP_LAUNCH(16);
+#undef SWP_LAUNCH
+        return A;
+    }
     if (!two && !unfused && (long)row_blocks * steps > 512) {
         // large system: panel once per step, then trailing update + next diagonal block in one launch
         if (steps <= 0) return A;

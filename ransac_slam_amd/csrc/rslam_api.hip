@@ -83,6 +83,7 @@ struct rslam_ctx {
     int store_cap = 0;
     bool patches_valid = false;           // d_patches holds the output of rslam_predict_patches for the current prediction
     DevBuf<int32_t> d_first;
+    DevBuf<int32_t> d_sweep_flags;        // hand-over flags of the persistent factor sweep (zeroed by prepare_system_kernel)
     // timing
     int timing = 0;
     hipEvent_t ev[EV_COUNT];
@@ -104,16 +105,24 @@ struct rslam_ctx {
     const int32_t* last_sup = nullptr;
     int reruns = 0;
     int graph_captures = 0;
+    int last_raw_status = 0;
     bool sweep_can_overflow = false;   // the update stage in flight was enqueued with a shortened sweep ...
     bool frame_checked = true;         // ... and read_status has (not) looked at it yet
 };
 
 // bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
+static bool sweep_is_persistent(const rslam_ctx* c)
+{
+    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
+    return sweep_persistent_eligible(d);
+}
+
 static void mark_update_enqueued(rslam_ctx* c, const int32_t* d_sup)
 {
     const int rp_blocks = c->RP / 64;
     c->last_sup = d_sup;
-    c->sweep_can_overflow = (c->cap_li < rp_blocks || c->cap_hi < rp_blocks);
+    // the persistent sweep is one launch sized for the largest inlier count: nothing to overflow
+    c->sweep_can_overflow = !sweep_is_persistent(c) && (c->cap_li < rp_blocks || c->cap_hi < rp_blocks);
     c->frame_checked = false;
     c->have_post = true;
 }
@@ -170,7 +179,7 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->ev_ok = (n_ev == EV_COUNT);
     if (!c->ev_ok) for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     memset(&c->times, 0, sizeof(c->times));
-    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
+    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0 || c->d_sweep_flags.ensure(SWEEP_FLAG_INTS) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     if (hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     *out = c;
@@ -193,7 +202,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_H13b.release(); c->d_S.release(); c->d_S2.release(); c->d_z.release(); c->d_wv.release();
     c->d_W.release(); c->d_A.release(); c->d_Y.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
-    c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release();
+    c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -449,7 +458,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
     int32_t* sel = c->d_sel.p;
     launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p,
-                          Wsrc, c->d_rank_of.p);
+                          Wsrc, c->d_rank_of.p, c->d_sweep_flags.p);
     if (ev_f0 >= 0) mark(c, ev_f0);
     const double* Ysys = c->d_A.p;        // the system whose lower rows hold Y = P H^T L^-T and u^T after the sweep
     {
@@ -462,7 +471,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         }
         const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
         Ysys = launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk,
-                                   cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS);
+                                   cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS, c->d_sweep_flags.p);
     }
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP <= 0) HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
@@ -491,14 +500,16 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
                    c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT);
         c->pht_done = true;
     }
+    const bool persistent = sweep_is_persistent(c);
+    const int cap_li = persistent ? (1 << 20) : c->cap_li, cap_hi = persistent ? (1 << 20) : c->cap_hi;
     // K5 consensus (Tracking.cpp:507-537)
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
-                     c->cfg.sigma_z, c->L, c->cap_li, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
+                     c->cfg.sigma_z, c->L, cap_li, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
                      c->cfg.adaptive, c->cfg.n_hyp_init);
     mark(c, EV_SELECT);
     // low-innovation update (ExtendKF.cpp:559-596)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
-    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, c->cap_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
+    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, cap_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
                                 c->d_Ppred.p, c->d_P.p, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0, EV_LI_RANK1);
     if (rc) return rc;
     mark(c, EV_LI_END);
@@ -507,13 +518,13 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
                    c->d_h2.p, c->d_hash2.p, nullptr, c->d_H13b.p, c->d_S2.p,
                    c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr);
     launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
-                       c->cap_hi, c->d_hi.p, c->d_hilist.p, sel);
+                       cap_hi, c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
     if (c->RP > 0)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
                    c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, c->cap_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
+    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, cap_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);
@@ -553,7 +564,11 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         if (rc) return rc;
     }
     if (sel[SEL_STATUS_FRONT] < sel[SEL_STATUS]) sel[SEL_STATUS] = sel[SEL_STATUS_FRONT];
-    if (c->have_meas && c->last_sup && sel[SEL_STATUS] == 0) {
+    if (sel[SEL_STATUS] <= -30) {                 // a bounded wait of the persistent sweep ran out: which one is kept for diagnosis
+        c->last_raw_status = sel[SEL_STATUS];
+        sel[SEL_STATUS] = RSLAM_ERR_HIP;
+    }
+    if (c->have_meas && c->last_sup && sel[SEL_STATUS] == 0 && !sweep_is_persistent(c)) {
         // grow at once (an overflow costs a re-run of the update stage); shrink at once when two or more block
         // steps are wasted, and by the last one only after the count has stayed lower for 8 frames (each change
         // of the launch sequence re-captures the hipGraphs; every empty step is two ~4.5 us launches)
@@ -1271,6 +1286,19 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(d, p + 192, 512, hipMemcpyDeviceToHost));
     return RSLAM_OK;
+}
+
+// diagnostic (not part of include/rslam.h): time stamps of the persistent factor sweep, see scripts/sweep_stamps.py
+namespace rslam { int debug_sweep_stamps(unsigned long long* out, int enable); }
+extern "C" int rslam_debug_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
+
+extern "C" int rslam_debug_sweep_stamps(rslam_ctx* c, unsigned long long* out, int enable)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    invalidate_graph(c);                      // captured launches hold the old debug pointer
+    return rslam::debug_sweep_stamps(out, enable) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
 }
 
 #if defined(CD_STAMPS)
