@@ -36,6 +36,7 @@ extern "C" {
                                         (compat mode, Tracking.cpp:498, m_euc != m_id)  */
 #define RSLAM_ERR_NOT_SPD        -6  /* innovation covariance not positive definite    */
 #define RSLAM_ERR_IC_NOT_VISIBLE -7  /* ic[i] set for a feature predicted not visible  */
+#define RSLAM_ERR_COMM           -8  /* RCCL not loadable or a collective failed        */
 
 #define RSLAM_FEAT_INVERSE_DEPTH 0   /* "inversedepth": 6 state entries (ExtendKF.cpp:71) */
 #define RSLAM_FEAT_CARTESIAN     1   /* "cartesian":    3 state entries (ExtendKF.cpp:80) */
@@ -245,13 +246,33 @@ int rslam_step_frame(rslam_ctx* ctx, int32_t use_graph);
 int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t hyp_end,
                      int32_t* d_supports, int32_t use_graph);
 
+/* The hypothesis-sharded frame of one rank in ONE call, for the C++ System loop that owns an RCCL
+ * communicator (one process per GPU; caller = the body of System::TrackRunning, System.cpp:117-129, on every rank):
+ * the draw list 0 .. n_draws-1 is cut into `world` contiguous slices of chunk = ceil(n_draws / world); this rank scores
+ * slice `rank` (phase 0 of rslam_step_phase), the int32 supports are exchanged with ONE ncclAllGather of chunk entries
+ * per rank on the context's stream (4 KB per 1000 hypotheses: latency-bound, never chunked), and every rank replays the
+ * consensus scan on the gathered list and applies both updates (phase 1): bit-identical posteriors on all ranks, no
+ * covariance broadcast.  nccl_comm is the caller's ncclComm_t (rccl.h) of `world` ranks; NULL is allowed for
+ * world == 1 (no collective).  RCCL is bound at the first call (the librccl.so.1 already in the process, else the
+ * system one): librslam_hip.so itself does not depend on it.  Every rank must have loaded the same frame
+ * (rslam_load_frame / rslam_load_measurements).  Stream-ordered like rslam_step_frame: results via rslam_sync and
+ * rslam_fetch_results. */
+int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph);
+
 /* Diagnostics of the resident pipeline since rslam_create (any pointer may be NULL): hipGraph captures
  * (a change of the launch sequence re-captures), update stages that had to be re-run because the
  * factor sweep had been enqueued too short for the frame's inlier count. */
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 
 /* Block until the stream is idle; returns the device-side status of the
- * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...). */
+ * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...).
+ * Frames may be enqueued back to back without rslam_sync: the factor sweep of an update is one persistent launch
+ * sized for the largest inlier count the frame can have.  Only systems too large for that path (more than 16 column
+ * blocks of S or more 16-row strips than compute units, e.g. 1000 landmarks) size their launch sequence from the
+ * previous frame's inlier counts; there an overflow is detected on the device and the update stage re-run by the next
+ * rslam_sync / rslam_fetch_* / rslam_ekf_prediction / rslam_map_* call, all of which check the frame in flight first --
+ * but a further rslam_step_* enqueued on top of an unchecked frame starts from a posterior that may still be re-run:
+ * sync such pipelines once per frame. */
 int rslam_sync(rslam_ctx* ctx);
 
 /* Results of the last frame (host pointers; any may be NULL). Synchronises. */

@@ -53,6 +53,7 @@ SYMBOLS = {
     "rslam_step_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rslam_step_phase": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "rslam_step_frame": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rslam_shard_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "rslam_sync": (C.c_int, [C.c_void_p]),
     "rslam_fetch_prediction": (C.c_int, [C.c_void_p, _dp, _u8p, _dp]),
     "rslam_fetch_results": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, _i32p, _i32p, _i32p, _i32p, _i32p]),
@@ -303,6 +304,11 @@ class RslamHip:
 
     def step_frame(self, use_graph=True):
         _chk(lib().rslam_step_frame(self._h, 1 if use_graph else 0), "rslam_step_frame")
+
+    def shard_frame(self, nccl_comm, rank, world, use_graph=True):
+        """one rank's hypothesis-sharded frame with the RCCL all-gather inside (nccl_comm: ncclComm_t as an int / c_void_p, or None)"""
+        _chk(lib().rslam_shard_frame(self._h, C.c_void_p(nccl_comm) if nccl_comm else None, rank, world, 1 if use_graph else 0),
+             "rslam_shard_frame")
 
     def sync(self):
         _chk(lib().rslam_sync(self._h), "rslam_sync")

@@ -44,6 +44,24 @@ def build_host_example(force=False):
     return HOST_EXAMPLE
 
 
+SHARD_EXAMPLE = os.path.join(HOST_DIR, "shard_frame_example")
+
+
+def build_shard_example(force=False):
+    """C++ driver of the hypothesis-sharded frame: one rank, RCCL communicator owned by the caller (links librccl)."""
+    srcs = [os.path.join(HOST_DIR, "shard_frame_example.cpp"), os.path.join(HOST_DIR, "ransac_slam_hip.hpp")]
+    if (not force and os.path.exists(SHARD_EXAMPLE)
+            and os.path.getmtime(SHARD_EXAMPLE) >= max(os.path.getmtime(f) for f in srcs + [LIB])):
+        return SHARD_EXAMPLE
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.dirname(HERE),
+                           "-I", os.path.join(rocm, "include"), srcs[0], "-o", SHARD_EXAMPLE,
+                           "-L", HERE, "-lrslam_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+                           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    return SHARD_EXAMPLE
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host_example())
+    print(build_shard_example())

@@ -12,6 +12,7 @@
 // d_sel[] on the device: no kernel launch depends on a host read-back, so a whole
 // frame is one stream-ordered (or hipGraph-replayed) launch sequence.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -83,6 +84,7 @@ struct rslam_ctx {
     int store_cap = 0;
     bool patches_valid = false;           // d_patches holds the output of rslam_predict_patches for the current prediction
     DevBuf<int32_t> d_first;
+    DevBuf<int32_t> d_sup_local, d_sup_all;   // rslam_shard_frame: this rank's slice of the supports, the gathered list
     DevBuf<int32_t> d_sweep_flags;        // hand-over flags of the persistent factor sweep (zeroed by prepare_system_kernel)
     // timing
     int timing = 0;
@@ -151,6 +153,7 @@ extern "C" const char* rslam_error_string(int code)
     case RSLAM_ERR_REF_ASSERT: return "input on which the reference hits an Eigen assertion (Tracking.cpp:498)";
     case RSLAM_ERR_NOT_SPD: return "innovation covariance not positive definite";
     case RSLAM_ERR_IC_NOT_VISIBLE: return "individually compatible flag on a feature that is not visible";
+    case RSLAM_ERR_COMM: return "RCCL could not be loaded or a collective failed";
     default: return "unknown error";
     }
 }
@@ -203,6 +206,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_W.release(); c->d_A.release(); c->d_Y.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
+    c->d_sup_local.release(); c->d_sup_all.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -1156,6 +1160,58 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
     if (rc) return rc;
     mark_update_enqueued(c, d_supports);
     return RSLAM_OK;
+}
+
+// ------------------------------------------------------------------------
+// hypothesis-sharded frame with the exchange inside (RCCL bound at run time)
+// ------------------------------------------------------------------------
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, void* /* ncclComm_t */, hipStream_t);
+constexpr int NCCL_INT32 = 2;               // ncclInt32 / ncclInt, rccl.h
+
+nccl_allgather_fn bind_allgather()
+{
+    static nccl_allgather_fn fn = []() -> nccl_allgather_fn {
+        // the RCCL the process already uses (the caller created its communicator with it), else the system one
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!sym) {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclAllGather");
+        }
+        return reinterpret_cast<nccl_allgather_fn>(sym);
+    }();
+    return fn;
+}
+}  // namespace
+
+extern "C" int rslam_shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world || (!nccl_comm && world > 1)) return RSLAM_ERR_ARG;
+    if (!c->have_state || !c->have_meas) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const int H = c->H;
+    const int chunk = (H + world - 1) / world > 0 ? (H + world - 1) / world : 1;
+    const int begin = rank * chunk < H ? rank * chunk : H;
+    const int end = begin + chunk < H ? begin + chunk : H;
+    int r1 = c->d_sup_local.ensure((size_t)chunk), r2 = c->d_sup_all.ensure((size_t)chunk * world);
+    if (r1 < 0 || r2 < 0) return RSLAM_ERR_HIP;
+    if (r1 > 0 || r2 > 0) {                    // new buffers: the graphs hold the old pointers; a short last slice leaves a tail
+        invalidate_graph(c);
+        HIPCHK(hipMemsetAsync(c->d_sup_local.p, 0, sizeof(int32_t) * chunk, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sup_all.p, 0, sizeof(int32_t) * (size_t)chunk * world, c->stream));
+    }
+    // phase 0 indexes the support array by global hypothesis id
+    int rc = rslam_step_phase(c, 0, begin, end, c->d_sup_local.p - begin, use_graph);
+    if (rc) return rc;
+    int32_t* full = c->d_sup_local.p;
+    if (nccl_comm) {
+        nccl_allgather_fn allgather = bind_allgather();
+        if (!allgather) return RSLAM_ERR_COMM;
+        if (allgather(c->d_sup_local.p, c->d_sup_all.p, (size_t)chunk, NCCL_INT32, nccl_comm, c->stream) != 0) return RSLAM_ERR_COMM;
+        full = c->d_sup_all.p;
+    }
+    return rslam_step_phase(c, 1, 0, H, full, use_graph);
 }
 
 extern "C" int rslam_sync(rslam_ctx* c)

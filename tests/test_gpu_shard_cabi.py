@@ -1,0 +1,115 @@
+"""The C-ABI route to the hypothesis-sharded frame: rslam_shard_frame with the RCCL all-gather inside.
+One GPU here, so the communicator has one rank (a self-gather through the real ncclAllGather on the
+context's stream); the slicing / consensus logic for world_size 2 is covered on CPU by
+tests/test_sharded_gloo.py and on one device over gloo by tests/test_gpu_configs.py."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from ransac_slam_amd import default_config
+from ransac_slam_amd.synth import make_frame
+
+pytestmark = pytest.mark.gpu
+
+
+class NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def _rccl():
+    for name in ("librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"):
+        try:
+            return C.CDLL(name, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    pytest.fail("RCCL is part of the image: librccl.so.1 must load")
+
+
+def _reference(hip, fr, cfg):
+    ref = hip.RslamHip(cfg)
+    ref.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    ref.step_frame(False); ref.sync()
+    full = ref.fetch_results()
+    ref.close()
+    return full
+
+
+def test_shard_frame_self_gather():
+    from ransac_slam_amd import api as hip
+    fr = make_frame(L=60, H=257, seed=302)
+    cfg = default_config(compat=0, adaptive=1)
+    full = _reference(hip, fr, cfg)
+    c = hip.RslamHip(cfg)                               # selects the device before RCCL is initialised
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    # world = 1 without a communicator: no collective
+    for _ in range(2):
+        c.shard_frame(None, 0, 1, True)
+    c.sync()
+    part = c.fetch_results()
+    assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+    # a communicator of one rank: the supports go through ncclAllGather on the context's stream
+    rccl = _rccl()
+    uid = NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        for use_graph in (False, True, True):
+            c.shard_frame(comm.value, 0, 1, use_graph)
+        c.sync()
+        part = c.fetch_results()
+        for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+            assert part[k] == full[k]
+        assert np.array_equal(part["li"], full["li"]) and np.array_equal(part["hi"], full["hi"])
+        assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+        # argument errors
+        with pytest.raises(hip.RslamError) as e:
+            c.shard_frame(None, 0, 2, True)             # two ranks need a communicator
+        assert e.value.code == -1
+        with pytest.raises(hip.RslamError) as e:
+            c.shard_frame(comm.value, 3, 2, True)
+        assert e.value.code == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+        c.close()
+
+
+@pytest.mark.parametrize("compat", [1, 0])
+def test_cpp_shard_frame_example(oracle_lib, tmp_path, compat):
+    """host/shard_frame_example.cpp (C++, owns the ncclComm_t) as rank 0 of 1, against the oracle."""
+    from ransac_slam_amd import build
+    build.build()
+    exe = build.build_shard_example()
+    fr = make_frame(L=60, H=1100, seed=501, frac_ic=0.9)
+    cfg = default_config(compat=compat, adaptive=1)
+    o = oracle_lib.Oracle(cfg, structure=1)
+    h0, v0, S0 = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z, ic, fr.draws)
+    fin, fout = tmp_path / "frame.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("4i", fr.n, fr.L, len(fr.draws), compat))
+        f.write(fr.types.tobytes()); f.write(fr.ic.astype(np.uint8).tobytes())
+        f.write(fr.x_pred.tobytes()); f.write(np.asfortranarray(fr.P_pred).tobytes(order="F"))
+        f.write(np.ascontiguousarray(fr.z).tobytes()); f.write(fr.draws.tobytes())
+    subprocess.check_call([exe, str(fin), str(fout)], timeout=300)
+    raw = open(fout, "rb").read()
+    n, L = fr.n, fr.L
+    sc = np.frombuffer(raw, np.int32, 3); p = 12
+    li = np.frombuffer(raw, np.uint8, L, p); p += L
+    hi = np.frombuffer(raw, np.uint8, L, p); p += L
+    vis = np.frombuffer(raw, np.uint8, L, p); p += L
+    p += 16 * L + 32 * L
+    x = np.frombuffer(raw, np.float64, n, p); p += 8 * n
+    P = np.frombuffer(raw, np.float64, n * n, p).reshape(n, n, order="F")
+    assert np.array_equal(vis, v0)
+    assert list(sc) == [r0["best_hyp"], r0["best_support"], r0["hyps_evaluated"]]
+    assert np.array_equal(li, r0["li"]) and np.array_equal(hi, r0["hi"])
+    assert np.max(np.abs(x - r0["x_new"])) <= 1e-9 * max(1.0, np.abs(r0["x_new"]).max())
+    assert np.max(np.abs(P - r0["P_new"])) <= 1e-9 * np.abs(r0["P_new"]).max()
