@@ -68,11 +68,19 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
                            const uint8_t* type, const double* z, const double* h, double* A,
                            const double* Wsrc, const int32_t* rank_of, int32_t* sweep_flags /* SWEEP_FLAG_INTS, zeroed here; nullable */);
 constexpr int SWEEP_FLAG_INTS = 112;   // hand-over flags of the persistent factor sweep (kernels.hip SweepFlags)
-bool sweep_persistent_eligible(const SystemDims& d);   // the whole sweep in one launch (no dependence on the previous frame's counts)
+bool sweep_persistent_eligible(const SystemDims& d);
+// What the persistent sweep builds its stacked system [S; P H^T; nu^T] from (it has no prepare_system pass): the
+// arguments of launch_prepare_system.  Wsrc != nullptr: P H^T columns come from the matched-feature matrix (LI pass),
+// else they are already in rows [RP, RP+NP) of A (HI pass: launch_pht wrote them there).
+struct SysSrc {
+    const int32_t* list; const double* H13; const int32_t* off; const uint8_t* type;
+    const double* z; const double* h; const double* Wsrc; const int32_t* rank_of;
+};   // the whole sweep in one launch (no dependence on the previous frame's counts)
 // returns the buffer (A or Ystore, same shape) whose rows [RP, RP + NP] hold Y and u^T afterwards
 double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
                             int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
-                            int32_t* status_sel, int32_t* flags /* SWEEP_FLAG_INTS zeroed ints, or nullptr: never the persistent sweep */);
+                            int32_t* status_sel, int32_t* flags /* 2 * SWEEP_FLAG_INTS zeroed ints, or nullptr: never the persistent sweep */,
+                            const SysSrc* src /* with flags: the sweep assembles the system itself (no launch_prepare_system) */);
 // K9 riding in the rank-update launch: the first `groups` workgroups compute x_k_k = x + Y u (16 rows each),
 // group 0 the quaternion normalisation and Jnorm, published through *flag = token (sel[SEL_XU_FLAG])
 struct XuArgs {

@@ -1385,10 +1385,33 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 
 // Eight waves: wave = 4 g + w.  Group g owns the column blocks j = 2 jj + g, wave w the columns 16 w .. 16 w + 15 of each.
+// column c of P H^T for the update at hand (row index = state index): gathered from the matched-feature matrix (LI pass)
+// or already in the P H^T rows of A (HI pass)
+__device__ __forceinline__ const double* sys_wcol(const SysSrc& s, const double* A, long ldA, int NP, int RP, int c)
+{
+    return s.Wsrc ? s.Wsrc + (long)(2 * s.rank_of[s.list[c >> 1]] + (c & 1)) * NP : A + RP + (long)c * ldA;
+}
+
+// S(a,c) = H_a (P H^T)_c + [a == c]  (ExtendKF.cpp:602 with R = I, :594; identity on the padding): what
+// prepare_system_kernel writes, computed where it is needed.  fa/Hf/o/w describe row a (fixed per lane).
+__device__ __forceinline__ double sys_S(const SysSrc& s, const double* A, long ldA, int NP, int RP, int r, int a, int c,
+                                        const double (&Hf)[13], int o, int w)
+{
+    double v = (a == c) ? 1.0 : 0.0;
+    if (a < r && c < r) {
+        const double* wc = sys_wcol(s, A, ldA, NP, RP, c);
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) if (k < w) sacc += Hf[k] * wc[col_index(o, k)];
+        v += sacc;
+    }
+    return v;
+}
+
 template <int NJ>
-__device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, int nblk, int strip,
-                                            const double* Linv, double* Ypanel, SweepFlags* fl, int32_t* status, double* lds,
-                                            unsigned long long* dbg)
+__device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, int nblk, int strip, int r_total, int NP,
+                                            const SysSrc& src, const double* Linv, double* Ypanel, SweepFlags* fl,
+                                            int32_t* status, double* lds, unsigned long long* dbg)
 {
     constexpr int NH = (NJ + 1) / 2;                        // column blocks per group
     const int b = strip >> 2;                               // 64-row block of the strip
@@ -1396,9 +1419,9 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     if (dbg) who = (strip == 8) ? 1 : (strip == 4 * (nblk - 1)) ? 2 : (strip == 4 * rp_blocks) ? 3 : (strip == (int)(ldA / 16) - 4) ? 4 : -1;
     if (who < 0) dbg = nullptr;
     const bool is_s = b < rp_blocks;
-    // padding rows of S; row block 0 is the first diagonal block only; row block 1 goes to the chain as it is prepared
-    if (is_s && (b >= nblk || b <= 1)) return;
+    if (is_s && b >= nblk) return;                          // padding rows of S
     if (b == (int)(ldA / 64) - 1 && (strip & 3) != 0) return;   // below nu^T there is only zero padding
+    const int RP = 64 * rp_blocks;
     const int ncols = is_s ? b + 1 : nblk;                  // column blocks held
     // steps k = 0 .. nsteps - 1, each followed by updates except the last of a P H^T strip.  S row block b stops after
     // step b-2: its step b-1 -- the panel block L(b,b-1) and the update of tile (b,b) -- is the chain's own prologue of
@@ -1412,17 +1435,55 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     int* abort = reinterpret_cast<int*>(lds + 2 * 64 * 16);
     bool alive = true;
     if (t == 0) *abort = 0;            // (the first wait has a barrier before anybody reads it)
-    // acc[jj][reg] of lane (ln, lq) = strip(ln, 64 (2 jj + g) + 16 w + lq + 4 reg)
+    // acc[jj][reg] of lane (ln, lq) = strip(ln, 64 (2 jj + g) + 16 w + lq + 4 reg); the strip assembles its rows of the
+    // stacked system itself (there is no prepare_system pass in front of this kernel)
     double* base = A + 16L * strip + ln + (64L * g + 16L * w + lq) * ldA;
     d4 acc[NH];
-    static_for<0, NH>([&](auto JJ) {
-        constexpr int jj = decltype(JJ)::value;
-        acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
-        if (2 * jj + g < ncols) {
+    {
+        const int row = 16 * strip + ln;                    // row of the stacked matrix
+        double Hf[13];
+        int fo = 0, fw = 0;
+        if (is_s && row < r_total) {                        // S row a = row: its Jacobian row, fixed for the lane
+            const int fa = src.list[row >> 1];
+            fo = src.off[fa]; fw = (src.type[fa] == 0) ? 13 : 10;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) acc[jj][reg] = base[(128L * jj + 4 * reg) * ldA];
+            for (int k = 0; k < 13; ++k) Hf[k] = src.H13[26L * fa + 13 * (row & 1) + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) Hf[k] = 0.0;
         }
-    });
+        const bool is_nu = (b == (int)(ldA / 64) - 1);
+        static_for<0, NH>([&](auto JJ) {
+            constexpr int jj = decltype(JJ)::value;
+            acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (2 * jj + g < ncols) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int c = 64 * (2 * jj + g) + 16 * w + lq + 4 * reg;
+                    double v = 0.0;
+                    if (is_s) v = sys_S(src, A, ldA, NP, RP, r_total, row, c, Hf, fo, fw);
+                    else if (c < r_total) {
+                        if (is_nu) { if (ln == 0) { const int f = src.list[c >> 1]; v = src.z[2 * f + (c & 1)] - src.h[2 * f + (c & 1)]; } }
+                        else v = sys_wcol(src, A, ldA, NP, RP, c)[row - RP];
+                    }
+                    acc[jj][reg] = v;
+                }
+            }
+        });
+    }
+    if (is_s && b <= 1) {
+        // Row blocks 0 and 1 go to the chain as they are assembled: tile (0,0); tiles (1,0), (1,1).  (Row block 1 has no
+        // step of its own: its panel block L(1,0) is the chain's prologue of diagonal block 1.)
+        static_for<0, (NH < 1 ? NH : 1)>([&](auto JJ) {
+            constexpr int jj = decltype(JJ)::value;
+            if (2 * jj + g <= b) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) st_coh(base + (128L * jj + 4 * reg) * ldA, acc[jj][reg]);
+            }
+        });
+        sw_post_add(&fl->row_ready[b]);
+        return;
+    }
     static_for<0, NJ>([&](auto K) {
         constexpr int k = decltype(K)::value;
         if (alive && k < nsteps) { sw_stamp(dbg, who, k, 0); alive = sw_wait(&fl->linv_ready, k + 1, status, abort, 1); sw_stamp(dbg, who, k, 1); }
@@ -1443,8 +1504,10 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     if (q < 4 * (w + 1)) x = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], Sk[(4 * q + lq) * 16 + ln], x, 0, 0, 0);
-                // x[reg] = X(ln, 16 w + lq + 4 reg): final.  P H^T / nu rows: Y in place; S rows: a panel block for the others
-                double* dst = (is_s ? Ypanel : A) + 16L * strip + ln + (64L * k + 16 * w + lq) * ldA;
+                // x[reg] = X(ln, 16 w + lq + 4 reg): final.  S rows: a panel block for the other strips; P H^T / nu rows: Y
+                // and u^T for the next kernel.  Both go to the second buffer: in the HI pass the rows of A below S are the
+                // P H^T that other strips may still be reading while they assemble their rows of S.
+                double* dst = Ypanel + 16L * strip + ln + (64L * k + 16 * w + lq) * ldA;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     if (is_s) st_coh(dst + (4L * reg) * ldA, x[reg]); else dst[(4L * reg) * ldA] = x[reg];
@@ -1738,7 +1801,7 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             CdpNext cur;
             cur.a_src = A + (long)k * 64 + row + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
             cur.tile = A + (long)k * 64 + (long)k * 64 * ldA;
-            cur.ldA = ldA; cur.flag = (k >= 2) ? &fl->row_ready[k] : nullptr; cur.Aop = Aop; cur.Tpre = Tpre;
+            cur.ldA = ldA; cur.flag = &fl->row_ready[k]; cur.Aop = Aop; cur.Tpre = Tpre;
             cdp_finish<TB>(cur, sh, pf, fetch_st);
         }
         __syncthreads();                                  // inputs of block k are in LDS
@@ -1789,7 +1852,7 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             CdpNext nx;
             nx.a_src = A + (long)(k + 1) * 64 + row + (long)k * 64 * ldA;
             nx.tile = A + (long)(k + 1) * 64 + (long)(k + 1) * 64 * ldA;
-            nx.ldA = ldA; nx.flag = (k + 1 >= 2) ? &fl->row_ready[k + 1] : nullptr; nx.Aop = Aop; nx.Tpre = Tpre;
+            nx.ldA = ldA; nx.flag = &fl->row_ready[k + 1]; nx.Aop = Aop; nx.Tpre = Tpre;
             fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, nx, want_next, pf, stamp, exp_mask);
         } else {
             cd_m_wave<ROLE - 2 - CD_TW>(sh, n_piv4, 0);
@@ -1834,16 +1897,21 @@ __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long
 
 template <int NJ>
 __global__ void __launch_bounds__(CD_THREADS)
-sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, int slot_nblk, int slot_k, int rp_blocks,
-                        double* Linv, double* Ypanel, int32_t* flags, int32_t* status, unsigned long long* dbg, int exp_mask)
+sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, int slot_nblk, int slot_k, int rp_blocks, int NP,
+                        SysSrc src, double* Linv, double* Ypanel, int32_t* flags, int32_t* flags_other, int32_t* status,
+                        unsigned long long* dbg, int exp_mask)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // The hand-over flags are double-buffered between the two sweeps of a frame: this launch uses `flags` (all zero:
+    // the previous sweep cleared them) and clears `flags_other` for the next one -- nobody is using that set now.
+    if (blockIdx.x == 0 && threadIdx.x < SWEEP_FLAG_INTS) flags_other[threadIdx.x] = 0;
     SweepFlags* fl = reinterpret_cast<SweepFlags*>(flags);
     int nblk = sel[slot_nblk];
     if (nblk > rp_blocks) nblk = rp_blocks;
     if (nblk <= 0) return;
-    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, Linv, Ypanel, fl, status, lds, dbg);
-    else cd_chain_persistent(lds, A, ldA, nblk, 2 * sel[slot_k], Linv, Ypanel, fl, status, dbg, exp_mask);
+    const int r_total = 2 * sel[slot_k];
+    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg);
+    else cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask);
 }
 
 // dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
@@ -1925,7 +1993,7 @@ bool sweep_persistent_eligible(const SystemDims& d)
 // sequence, A itself for the others.
 double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
                             const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
-                            int32_t* status_sel, int32_t* flags)
+                            int32_t* status_sel, int32_t* flags, const SysSrc* src)
 {
     const int rp_blocks = d.RP / 64;
     const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
@@ -1933,18 +2001,21 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
     const bool two = (aux != nullptr && ev != nullptr);
     static const bool unfused = getenv("RSLAM_SWEEP_UNFUSED") != nullptr;
-    if (!two && !unfused && flags && sweep_persistent_eligible(d)) {
+    if (!two && !unfused && flags && src && sweep_persistent_eligible(d)) {
         // one launch for the whole sweep, sized for the largest inlier count the frame can have: the launch sequence
         // never depends on the previous frame (cap_blocks is not used)
         const dim3 grid(1 + d.ldA / 16), block(CD_THREADS);
         static const int exp_mask = getenv("RSLAM_SWEEP_EXP") ? atoi(getenv("RSLAM_SWEEP_EXP")) : 0;   // measurement switches
-#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, Linv, Ystore, flags, status_sel, g_sweep_dbg, exp_mask)
+        const int set = (slot_k == SEL_K_LI) ? 0 : 1;              // the LI and the HI sweep of a frame alternate between the two flag sets
+        int32_t* fl_cur = flags + set * SWEEP_FLAG_INTS;
+        int32_t* fl_other = flags + (1 - set) * SWEEP_FLAG_INTS;
+#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, g_sweep_dbg, exp_mask)
         if (rp_blocks <= 4) SWP_LAUNCH(4);
         else if (rp_blocks <= 8) SWP_LAUNCH(8);
         else if (rp_blocks <= 12) SWP_LAUNCH(12);
         else SWP_LAUNCH(16);
 #undef SWP_LAUNCH
-        return A;
+        return Ystore;
     }
     if (!two && !unfused && (long)row_blocks * steps > 512) {
         // large system: panel once per step, then trailing update + next diagonal block in one launch

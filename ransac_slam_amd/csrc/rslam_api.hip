@@ -182,8 +182,9 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->ev_ok = (n_ev == EV_COUNT);
     if (!c->ev_ok) for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     memset(&c->times, 0, sizeof(c->times));
-    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0 || c->d_sweep_flags.ensure(SWEEP_FLAG_INTS) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
-    if (hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, c->stream) != hipSuccess ||
+    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0 || c->d_sweep_flags.ensure(2 * SWEEP_FLAG_INTS) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
+    if (hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     *out = c;
     return RSLAM_OK;
@@ -461,8 +462,13 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     hipStream_t s = c->stream;
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
     int32_t* sel = c->d_sel.p;
-    launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p,
-                          Wsrc, c->d_rank_of.p, c->d_sweep_flags.p);
+    // The persistent sweep assembles the stacked system itself; the launch-per-step sequence of large systems has a pass
+    // of its own for that.
+    const bool persistent = sweep_is_persistent(c);
+    SysSrc src{list, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, Wsrc, c->d_rank_of.p};
+    if (!persistent)
+        launch_prepare_system(s, d, list, sel, slot_k, slot_nblk, H13, c->d_off.p, c->d_type.p, c->d_z.p, z_h, c->d_A.p,
+                              Wsrc, c->d_rank_of.p, nullptr);
     if (ev_f0 >= 0) mark(c, ev_f0);
     const double* Ysys = c->d_A.p;        // the system whose lower rows hold Y = P H^T L^-T and u^T after the sweep
     {
@@ -475,7 +481,8 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         }
         const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
         Ysys = launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk,
-                                   cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS, c->d_sweep_flags.p);
+                                   cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
+                                   persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr);
     }
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP <= 0) HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
