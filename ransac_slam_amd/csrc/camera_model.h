@@ -14,6 +14,7 @@ namespace rslam {
 struct Cam {
     double k1, k2, Cx, Cy, f, dx, dy;
     int nRows, nCols;
+    double inv_dx, inv_dy, f_ku;     // 1/dx, 1/dy, f * (1/dx): correctly rounded on the host once (scoring kernel)
 };
 
 // ExtendKF::q2r (src/ExtendKF.cpp:91-102); q = (r,x,y,z); R column-major.
@@ -59,6 +60,57 @@ __device__ __forceinline__ void inv2_lu(const double M[4], double R[4])
     R[0] = x0; R[1] = x1;
     y1 = e1b - l * e1a;  x1 = y1 / u11;  x0 = (e1a - b * x1) / a;
     R[2] = x0; R[3] = x1;
+}
+
+// 1/d to full double precision without the IEEE division sequence: v_rcp_f64 (~2^-26) and two Newton steps
+__device__ __forceinline__ double rcp_nr2(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// distort_fm for the hypothesis scoring (Tracking.cpp:472-476 only compares the result with a threshold; the decisions
+// are audited for a 1e-9 margin, the values need not be bit-identical to a divide-based evaluation).  The reference's
+// 10 Newton steps divide by the slope f'(rd); any factor within 2^-26 of 1/f' gives the same fixed point -- the error of
+// step n+1 is eps * (error of step n) + O(error^2) -- so the slope reciprocal is the raw v_rcp_f64.  The divisions that
+// enter the result (1/D, 1/dx, 1/dy) are full-precision reciprocals (dx, dy: from the host).
+__device__ __forceinline__ void distort_fm_score(const Cam& cam, double u, double v, double& ud, double& vd)
+{
+    const double xu = (u - cam.Cx) * cam.dx;
+    const double yu = (v - cam.Cy) * cam.dy;
+    const double ru = sqrt(xu * xu + yu * yu);
+    const double ru2 = ru * ru;
+    double rd = ru * __builtin_amdgcn_rcp(1 + cam.k1 * ru2 + cam.k2 * (ru2 * ru2));     // starting point only
+    const double k1_3 = 3 * cam.k1, k2_5 = 5 * cam.k2;
+#pragma unroll
+    // Six steps reach the fixed point the reference's ten reach: the starting point is within ~1e-2 relative, the steps
+    // converge quadratically (1e-4, 1e-8, ...) until the 2^-26 slope error makes them linear with that factor.
+    for (int k = 0; k < 6; ++k) {
+        const double rd2 = rd * rd, rd4 = rd2 * rd2;
+        const double f = rd + cam.k1 * (rd2 * rd) + cam.k2 * (rd4 * rd) - ru;
+        const double fp = 1 + k1_3 * rd2 + k2_5 * rd4;
+        rd = rd - f * __builtin_amdgcn_rcp(fp);
+    }
+    const double rd2 = rd * rd;
+    const double rD = rcp_nr2(1 + cam.k1 * rd2 + cam.k2 * (rd2 * rd2));
+    ud = (xu * rD) * cam.inv_dx + cam.Cx;
+    vd = (yu * rD) * cam.inv_dy + cam.Cy;
+}
+
+// sin / cos of (a0 + d) from the tabulated sin a0, cos a0 and a short series in d (|d| <= 1/8: the truncation error of
+// both series is < 1e-19): the scoring kernel evaluates every feature's angles once per hypothesis, where they differ from
+// the prior's angles only by the hypothesis' state correction.
+__device__ __forceinline__ void sincos_delta(double s0, double c0, double d, double& s, double& c)
+{
+    const double q = d * d;
+    const double sd = d * fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, 1.0 / 6227020800.0, -1.0 / 39916800.0), 1.0 / 362880.0), -1.0 / 5040.0),
+                                         1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const double cd = fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, 1.0 / 479001600.0, -1.0 / 3628800.0), 1.0 / 40320.0), -1.0 / 720.0),
+                                    1.0 / 24.0), -0.5), 1.0);
+    s = fma(s0, cd, c0 * sd);
+    c = fma(c0, cd, -(s0 * sd));
 }
 
 // ExtendKF::distort_fm (src/ExtendKF.cpp:175-204): 10 fixed Newton steps.

@@ -27,6 +27,7 @@ struct ScoreTables {          // per matched feature (rank j in feature order), 
     const int32_t* ith;       // state index read as theta (Q1 in compat mode)
     const int32_t* iph;       // state index read as phi
     const int32_t* zsrc;      // feature whose z is compared (Q2 in compat mode)
+    const double* sc;         // 4 per matched feature: sin, cos of x[ith], sin, cos of x[iph] at the prior (written by launch_pht)
 };
 
 // h_in / has_h_in: previous prediction (nullable); sel_reset: frame scalars to zero (nullable)
@@ -39,7 +40,9 @@ void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count /* nullable */, const double* H13, const int32_t* off,
                 const uint8_t* type, double* out, long ldo, const double* S, const double* z, const double* h,
-                const uint8_t* has_h, double* wv, int32_t* status);
+                const uint8_t* has_h, double* wv, int32_t* status,
+                const double* x = nullptr, const int32_t* ith = nullptr, const int32_t* iph = nullptr, double* sc = nullptr /* with wv:
+                the angle table of ScoreTables::sc */);
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                   const double* wv, const ScoreTables& tab, const double* z, int m, int words,

@@ -110,6 +110,7 @@ void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double
 // ---------------------------------------------------------------------------
 struct InnovArgs {            // all nullable together
     const double* S; const double* z; const double* h; const uint8_t* has_h; double* wv; int32_t* status;
+    const double* x; const int32_t* ith; const int32_t* iph; double* sc;      // angle table of the scoring kernel (nullable)
 };
 
 __global__ void __launch_bounds__(256)
@@ -122,6 +123,11 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
     const int count = d_count ? *d_count : max_count;
     if (c >= count) return;
     const int f = list[c];
+    if (iv.sc && blockIdx.x == 0 && threadIdx.x == 1) {
+        double sv, cv;
+        sincos(iv.x[iv.ith[c]], &sv, &cv); iv.sc[4 * c] = sv; iv.sc[4 * c + 1] = cv;
+        sincos(iv.x[iv.iph[c]], &sv, &cv); iv.sc[4 * c + 2] = sv; iv.sc[4 * c + 3] = cv;
+    }
     if (iv.wv && blockIdx.x == 0 && threadIdx.x == 0) {
         if (!iv.has_h[f]) {                     // matching() only produces z where h exists (Tracking.cpp:293)
             atomicMin(iv.status, -7);           // RSLAM_ERR_IC_NOT_VISIBLE
@@ -152,10 +158,10 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count, const double* H13, const int32_t* off, const uint8_t* type,
                 double* out, long ldo, const double* S, const double* z, const double* h, const uint8_t* has_h,
-                double* wv, int32_t* status)
+                double* wv, int32_t* status, const double* x, const int32_t* ith, const int32_t* iph, double* sc)
 {
     if (max_count <= 0) return;
-    InnovArgs iv{S, z, h, has_h, wv, status};
+    InnovArgs iv{S, z, h, has_h, wv, status, x, ith, iph, sc};
     pht_kernel<<<dim3(NP / 256 + (NP % 256 ? 1 : 0), max_count), dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv);
 }
 
@@ -197,10 +203,19 @@ __device__ __forceinline__ bool score_pair(const Cam& cam, const double* __restr
     double v[3];
     const double r0 = XI(o), r1 = XI(o + 1), r2 = XI(o + 2);
     if (tab.type[j] == 0) {
-        const double th = XI(tab.ith[j]), ph = XI(tab.iph[j]), rho = XI(o + 5);
+        const int ith = tab.ith[j], iph = tab.iph[j];
+        const double rho = XI(o + 5);
+        // the angles are the prior's plus the hypothesis' correction: tabulated sin / cos and a short series in the
+        // correction (two full sincos per pair were a third of this kernel); a large correction takes the long way
+        const double dth = hc.c0[ith] * hc.w0 + hc.c1[ith] * hc.w1, dph = hc.c0[iph] * hc.w0 + hc.c1[iph] * hc.w1;
         double st, ct, sp, cp;
-        sincos(th, &st, &ct);
-        sincos(ph, &sp, &cp);
+        if (fabs(dth) <= 0.125 && fabs(dph) <= 0.125) {
+            sincos_delta(tab.sc[4 * j], tab.sc[4 * j + 1], dth, st, ct);
+            sincos_delta(tab.sc[4 * j + 2], tab.sc[4 * j + 3], dph, sp, cp);
+        } else {
+            sincos(x[ith] + dth, &st, &ct);
+            sincos(x[iph] + dph, &sp, &cp);
+        }
         v[0] = (r0 - hc.pose[0]) * rho + cp * st;
         v[1] = (r1 - hc.pose[1]) * rho + (-sp);
         v[2] = (r2 - hc.pose[2]) * rho + cp * ct;
@@ -211,14 +226,16 @@ __device__ __forceinline__ bool score_pair(const Cam& cam, const double* __restr
     const double h0 = hc.rot[0] * v[0] + hc.rot[3] * v[1] + hc.rot[6] * v[2];
     const double h1 = hc.rot[1] * v[0] + hc.rot[4] * v[1] + hc.rot[7] * v[2];
     const double h2 = hc.rot[2] * v[0] + hc.rot[5] * v[1] + hc.rot[8] * v[2];
-    const double fku = cam.f * (1 / cam.dx);           // Tracking.cpp:471: ku on both axes
-    const double ui = fku * (h0 / h2) + cam.Cx;
-    const double vi = fku * (h1 / h2) + cam.Cy;
+    // Tracking.cpp:471: ku on both axes.  One full-precision reciprocal instead of two divisions; the residual is compared
+    // squared (sqrt is monotonic; the decisions carry a 1e-9 margin audit, see distort_fm_score)
+    const double rh2 = rcp_nr2(h2);
+    const double ui = cam.f_ku * (h0 * rh2) + cam.Cx;
+    const double vi = cam.f_ku * (h1 * rh2) + cam.Cy;
     double ud, vd;
-    distort_fm(cam, ui, vi, ud, vd);
+    distort_fm_score(cam, ui, vi, ud, vd);
     const int zf = tab.zsrc[j];
     const double n0 = z[2 * zf] - ud, n1 = z[2 * zf + 1] - vd;
-    return sqrt(n0 * n0 + n1 * n1) < thr;
+    return (n0 * n0 + n1 * n1) < thr * thr;
 }
 
 __global__ void __launch_bounds__(1024)

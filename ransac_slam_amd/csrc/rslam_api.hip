@@ -74,7 +74,7 @@ struct rslam_ctx {
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Y, d_Linv,
-                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr;
+                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr, d_sc;
     DevBuf<uint8_t> d_image;
     // feature store: initialisation records of Map::initialize_a_features (Map.cpp:286-292), one slot per feature
     DevBuf<double> d_rec;                 // slot * 14: uv(2) R(9 col-major) r(3)
@@ -170,6 +170,7 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->cfg = *cfg;
     c->cam.k1 = cfg->cam.k1; c->cam.k2 = cfg->cam.k2; c->cam.Cx = cfg->cam.Cx; c->cam.Cy = cfg->cam.Cy;
     c->cam.f = cfg->cam.f; c->cam.dx = cfg->cam.dx; c->cam.dy = cfg->cam.dy;
+    c->cam.inv_dx = 1.0 / cfg->cam.dx; c->cam.inv_dy = 1.0 / cfg->cam.dy; c->cam.f_ku = cfg->cam.f * (1.0 / cfg->cam.dx);
     c->cam.nRows = cfg->cam.nRows; c->cam.nCols = cfg->cam.nCols;
     c->device = device;
     // every failure path below goes through rslam_destroy, which releases whatever exists so far
@@ -208,7 +209,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
     c->d_sup_local.release(); c->d_sup_all.release();
-    c->d_patches.release(); c->d_corr.release(); c->d_image.release();
+    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_sc.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
@@ -360,7 +361,7 @@ static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic,
     ENS(c->d_pos, H); ENS(c->d_nhyp, (size_t)m + 1); ENS(c->d_sup, H); ENS(c->d_possup, m);
     ENS(c->d_masks, (size_t)H * (words ? words : 1)); ENS(c->d_posmask, (size_t)m * (words ? words : 1));
     ENS(c->d_lilist, m); ENS(c->d_hilist, m);
-    ENS(c->d_wv, 2 * (size_t)m); ENS(c->d_W, (size_t)c->NP * 2 * (m ? m : 1));
+    ENS(c->d_sc, 4 * (size_t)m); ENS(c->d_wv, 2 * (size_t)m); ENS(c->d_W, (size_t)c->NP * 2 * (m ? m : 1));
     ENS(c->d_A, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Y, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Linv, (size_t)64 * 64 * (RP / 64 ? RP / 64 : 1));
     if (re) invalidate_graph(c);
 #undef ENS
@@ -388,7 +389,7 @@ static ScoreTables tables(rslam_ctx* c)
 {
     ScoreTables t;
     t.feat = c->d_mfeat.p; t.off = c->d_moff.p; t.type = c->d_mtype.p;
-    t.ith = c->d_mith.p; t.iph = c->d_miph.p; t.zsrc = c->d_mzsrc.p;
+    t.ith = c->d_mith.p; t.iph = c->d_miph.p; t.zsrc = c->d_mzsrc.p; t.sc = c->d_sc.p;
     return t;
 }
 
@@ -413,7 +414,8 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     hipStream_t s = c->stream;
     if (!c->pht_done) {
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
-                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT);
+                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT,
+                   c->d_xpred.p, c->d_mith.p, c->d_miph.p, c->d_sc.p);
         c->pht_done = true;
     }
     mark(c, EV_PHT);
@@ -508,7 +510,8 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     mark_update_enqueued(c, d_sup);
     if (!c->pht_done) {   // update without a local score pass (supports came from elsewhere)
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
-                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT);
+                   c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT,
+                   c->d_xpred.p, c->d_mith.p, c->d_miph.p, c->d_sc.p);
         c->pht_done = true;
     }
     const bool persistent = sweep_is_persistent(c);
