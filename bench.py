@@ -37,7 +37,7 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_bench_c3_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bench_c3_pmc_summary.csv")
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -241,7 +241,8 @@ def main():
     ap.add_argument("--compat", type=int, default=1, help="1 = reference-identical arithmetic (default), 0 = corrected")
     ap.add_argument("--dedup", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-sample-iters", type=int, default=300)
+    ap.add_argument("--cpu-sample-iters", type=int, default=1000,
+                    help="RANSAC iterations of the CPU baseline actually timed (default: all 1000 of C3 = one whole frame, ~6 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()

@@ -242,3 +242,39 @@ def test_unsynced_frame_into_ekf_prediction(hip, oracle_lib):
     xp1, Pp1 = g.fetch_prior()
     assert close_x(xp1, xp0) and close_P(Pp1, Pp0)
     g.close()
+
+
+# --------------------------------------------------------------------------- frame sequence on the resident prior
+@pytest.mark.parametrize("compat", [1, 0])
+def test_sequence_of_measurements_on_resident_prior(hip, oracle_lib, compat):
+    """What bench.py's `sequence` key times: distinct measurements per frame through rslam_load_measurements +
+    rslam_step_frame(hipGraph) with no covariance traffic and back-to-back frames without a sync in between;
+    every frame against the oracle, and the launch sequence must not change (one capture, no re-run)."""
+    from ransac_slam_amd.synth import remeasure
+    fr = make_frame(L=120, H=300, seed=901)
+    cfg = default_config(compat=compat, adaptive=1)
+    g = hip.RslamHip(cfg)
+    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    g.step_predict(); g.sync()
+    ic = (fr.ic & g.fetch_prediction()[1]).astype(np.uint8)
+    c0 = None
+    for k, frac in enumerate((0.05, 0.6, 0.2, 0.9, 0.0)):
+        z, _, draws = remeasure(fr, 40 + k, frac_outlier=frac)
+        o = oracle_lib.Oracle(cfg, structure=1)
+        o.predict(fr.types, fr.x_pred, fr.P_pred)
+        r0 = o.ransac_update(z, ic, draws)
+        assert min(o.margins()) > 1e-9
+        g.load_measurements(z, ic, draws)
+        g.step_frame(True)
+        g.step_frame(True)                       # replayed on top of the first, no sync in between
+        g.sync()
+        r1 = g.fetch_results()
+        for key in ("best_hyp", "best_support", "hyps_evaluated"):
+            assert r1[key] == r0[key], (k, key)
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+        if c0 is None:
+            c0 = g.counters()
+    c1 = g.counters()
+    assert c1["graph_captures"] == c0["graph_captures"] and c1["sweep_reruns"] == 0
+    g.close()
