@@ -276,5 +276,6 @@ def test_sequence_of_measurements_on_resident_prior(hip, oracle_lib, compat):
         if c0 is None:
             c0 = g.counters()
     c1 = g.counters()
-    assert c1["graph_captures"] == c0["graph_captures"] and c1["sweep_reruns"] == 0
+    if not os.environ.get("RSLAM_SWEEP_STEPS"):          # (the launch-per-step sweep, kept for measurement, re-captures by design)
+        assert c1["graph_captures"] == c0["graph_captures"] and c1["sweep_reruns"] == 0
     g.close()
