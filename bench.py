@@ -335,6 +335,30 @@ def main():
                          "config": config_of(c4, WORKLOADS["C4"])}
         c4.ctx.close()
 
+    # ---- BASELINE config C5 (1000 landmarks, n = 6013): the MFMA-utilisation stress configuration, single GPU only
+    if not args.no_extras and args.workload != "C5" and world == 1 and rank == 0:
+        c5 = Runner(args, WORKLOADS["C5"], world, rank, local_rank, args.compat, use_graph)
+        k5 = max(5, min(args.steps, 20))
+        e5 = c5.timed(k5, 2, repeats=1)
+        r5 = c5.result()
+        c5.ctx.enable_timing(True)
+        acc5 = {}
+        for _ in range(3):
+            c5.ctx.step_frame(False); c5.ctx.sync()
+        for _ in range(5):
+            c5.ctx.step_frame(False); c5.ctx.sync()
+            for kk, vv in c5.ctx.timings().items():
+                acc5[kk] = acc5.get(kk, 0.0) + vv / 5
+        n5 = int(c5.frame.n)
+        us5, rr5 = max((acc5["rank_update_hi_us"], 2 * r5["n_hi"]), (acc5["rank_update_li_us"], 2 * r5["n_li"]))
+        f5 = float(n5) * (n5 + 1) * rr5
+        out["c5"] = {"ms_per_step": e5 / k5 * 1e3, "steps": k5, "result": r5, "config": config_of(c5, WORKLOADS["C5"]),
+                     "stage_us": {kk: round(vv, 1) for kk, vv in acc5.items()},
+                     "rank_update": {"launch_us": us5, "rank_r": rr5, "achieved_TFLOPs": f5 / (us5 * 1e-6) * 1e-12 if us5 > 0 else 0.0,
+                                     "frac_of_fp64_mfma_peak": f5 / (us5 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if us5 > 0 else 0.0},
+                     "note": "too large for the persistent sweep (508 strips > CUs): launch-per-step sweep, sized from the previous frame"}
+        c5.ctx.close()
+
     # ---- per-kernel durations (HIP events on the launch stream, eager frames) ----
     if rank == 0 and world == 1:
         ctx.enable_timing(True)

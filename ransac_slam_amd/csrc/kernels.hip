@@ -2179,7 +2179,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     }
     TgAcc acc;
     tg_zero(acc);
-    tile_gemm_nt(Y + (long)bi * 64, ldy, Y + (long)bj * 64, ldy, K, lds, acc);
+    tile_gemm_nt_dma(Y + (long)bi * 64, ldy, Y + (long)bj * 64, ldy, K, lds, acc);
     double* Cs = lds;
     double* Ts = lds + TS_DOUBLES;
     tg_acc_to_lds(acc, Cs, 1.0);
@@ -2438,7 +2438,7 @@ gemm_nt_kernel(int K, double alpha, const double* __restrict__ A, long lda, cons
     const int bi = blockIdx.x, bj = blockIdx.y;
     TgAcc acc;
     tg_zero(acc);
-    tile_gemm_nt(A + (long)bi * 64, lda, B + (long)bj * 64, ldb, K, lds, acc);
+    tile_gemm_nt_dma(A + (long)bi * 64, lda, B + (long)bj * 64, ldb, K, lds, acc);
     tg_acc_to_lds(acc, lds, alpha);
     __syncthreads();
     double* Ct = C + (long)bi * 64 + (long)bj * 64 * ldc;

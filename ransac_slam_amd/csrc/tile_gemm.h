@@ -220,6 +220,101 @@ __device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ A, long 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same engine with LDS-DMA staging (global_load_lds_dwordx4): the operand chunks go from global memory straight
+// into LDS -- no VGPR round trip, no ds_write, no staging registers -- which the register-staged loop above pays with
+// ~13 % of its rate (scripts/gemm_bench.py ablations).  One wave instruction writes 1 KiB contiguously (wave-uniform
+// base + lane x 16 B), so padding cannot go inside it; instead each instruction fetches TWO k-rows that are never read
+// by the same half-wave: lanes 0..31 row 4s + par, lanes 32..63 row 4s + par + 2 (64 doubles each), par = segment & 1.
+// Segments are 1152 B apart (1 KiB + 128 B), so for a fragment read (lane = (kq, ij), k = 4s + kq) the half-wave
+// {kq 0, 1} finds its two rows at byte offsets 0 and 1152 = 128 (mod 256) and {kq 2, 3} at 512 and 1664 = 128 (mod 256):
+// each half-wave covers all 64 banks exactly once, as with the padded image.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TD_SEG = 144;                               // doubles between segments
+constexpr int TD_STEP = 2 * TD_SEG;                       // doubles per k-step (4 rows)
+constexpr int TD_OPER_DOUBLES = (TG_KC / 2) * TD_SEG;     // one operand, one chunk: 16 segments
+constexpr int TD_LDS_DOUBLES = 4 * TD_OPER_DOUBLES;       // A, B x 2 buffers = 72 KiB
+typedef __attribute__((address_space(3))) void tg_lds_void;
+typedef __attribute__((address_space(1))) const void tg_glb_void;
+
+// chunk k0 .. k0 + TG_KC of both operands -> LDS images As, Bs; four segments per wave and operand
+__device__ __forceinline__ void td_issue_chunk(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                               int k0, double* As, double* Bs)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = 2 * (lane & 31), up = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < TG_KC / 8; ++q) {
+        const int sg = wave + 4 * q;                      // segment: k-step sg >> 1, parity sg & 1
+        const long k = k0 + 4 * (sg >> 1) + (sg & 1) + 2 * up;
+        __builtin_amdgcn_global_load_lds((tg_glb_void*)(A + r + k * lda), (tg_lds_void*)(As + sg * TD_SEG), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((tg_glb_void*)(B + r + k * ldb), (tg_lds_void*)(Bs + sg * TD_SEG), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / TG_WN, wn = wave % TG_WN;
+    const int kq = lane >> 4, ij = lane & 15;
+    const int koff = (kq & 1) * TD_SEG + (kq >> 1) * 64;
+    const double* ap = As + koff + wm * 16 * TG_MI + ij;
+    const double* bb = Bs + koff + wn * 16 * TG_NI;
+    const double* bp0 = bb + ij;
+    const double* bp1 = bb + ((ij - 4) & 15);
+    const double* bp2 = bb + ((ij - 8) & 15);
+    const double* bp3 = bb + ((ij - 12) & 15);
+    double a[TG_MI];
+    BFrag b[TG_NI];
+#pragma unroll
+    for (int mi = 0; mi < TG_MI; ++mi) a[mi] = ap[16 * mi];
+#pragma unroll
+    for (int ni = 0; ni < TG_NI; ++ni) b[ni] = BFrag{ bp0[16 * ni], bp1[16 * ni], bp2[16 * ni], bp3[16 * ni] };
+#pragma unroll
+    for (int kk = 0; kk < TG_KC; kk += 4) {
+        double na[TG_MI];
+        BFrag nb[TG_NI];
+        if (kk + 4 < TG_KC) {
+            const int o = (kk / 4 + 1) * TD_STEP;
+#pragma unroll
+            for (int mi = 0; mi < TG_MI; ++mi) na[mi] = ap[o + 16 * mi];
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) nb[ni] = BFrag{ bp0[o + 16 * ni], bp1[o + 16 * ni], bp2[o + 16 * ni], bp3[o + 16 * ni] };
+        }
+#pragma unroll
+        for (int mi = 0; mi < TG_MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) tg_mma_16x16x4(a[mi], b[ni], acc[mi][ni]);
+        if (kk + 4 < TG_KC) {
+#pragma unroll
+            for (int mi = 0; mi < TG_MI; ++mi) a[mi] = na[mi];
+#pragma unroll
+            for (int ni = 0; ni < TG_NI; ++ni) b[ni] = nb[ni];
+        }
+    }
+}
+
+// acc += A(64 x K) * B(64 x K)^T, LDS-DMA staged.  lds holds TD_LDS_DOUBLES.  Ends with a barrier.
+__device__ __forceinline__ void tile_gemm_nt_dma(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                 int K, double* lds, TgAcc& acc)
+{
+    double* As0 = lds;
+    double* Bs0 = lds + TD_OPER_DOUBLES;
+    double* As1 = lds + 2 * TD_OPER_DOUBLES;
+    double* Bs1 = lds + 3 * TD_OPER_DOUBLES;
+    const int nchunks = K / TG_KC;
+    if (nchunks <= 0) return;
+    td_issue_chunk(A, lda, B, ldb, 0, As0, Bs0);
+    __syncthreads();                                      // (a barrier waits for this wave's DMA: vmcnt(0))
+    for (int c = 0; c < nchunks; ++c) {
+        // chunk c+1 flies into the other buffer (everybody left it at the last barrier) under the MFMAs of chunk c
+        if (c + 1 < nchunks) { if (c & 1) td_issue_chunk(A, lda, B, ldb, (c + 1) * TG_KC, As0, Bs0); else td_issue_chunk(A, lda, B, ldb, (c + 1) * TG_KC, As1, Bs1); }
+        if (c & 1) td_compute_chunk(As1, Bs1, acc); else td_compute_chunk(As0, Bs0, acc);
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void tg_zero(TgAcc& acc)
 {
 #pragma unroll
@@ -233,6 +328,7 @@ __device__ __forceinline__ void tg_zero(TgAcc& acc)
 constexpr int TS_LD = 65;
 constexpr int TS_DOUBLES = 64 * TS_LD;
 static_assert(TG_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 tiles in the operand buffers");
+static_assert(TD_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 tiles in the operand buffers");
 
 template <int LD = 65>
 __device__ __forceinline__ void tg_acc_to_lds(const TgAcc& acc, double* Cs, double scale)
