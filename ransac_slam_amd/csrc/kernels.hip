@@ -979,7 +979,7 @@ __device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict_
             }
         }
     }
-    if (pending >= 2) {
+    if (pending == 2) {
         const double* Ag = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
         const double* Lg = Linv + (long)(step - 1) * 64 * 64;
         const int row = t & 63, g = t >> 6;
@@ -987,22 +987,18 @@ __device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict_
         for (int q = 0; q < 64 / (CD_THREADS / 64); ++q) {
             const int m = g + (CD_THREADS / 64) * q;
             pre.a[q] = Ag[row + (long)m * ldA];
-            if (pending == 2) pre.l[q] = Lg[row + 64 * m];      // pending 3: L^-1 of the previous block is still in LDS
+            pre.l[q] = Lg[row + 64 * m];
         }
     }
 }
 
 // pending: 0 nothing; 1 lookahead (the panel X = A(k,k-1) is in global memory, T -= X X^T is applied here);
-//          2 single-launch block step (X is formed here from A(k,k-1) and L^-1(k-1), both preloaded from global memory);
-//          3 persistent sweep (as 2, but L^-1(k-1) is what this workgroup left in sh.Mf and A(k,k-1) is staged in
-//            `aop_ext`, a 64 x CD_OPLD buffer behind the CdShared; L is not written back: nobody reads it).
+//          2 single-launch block step (X is formed here from A(k,k-1) and L^-1(k-1), both preloaded from global memory).
+// (The persistent sweep has its own block loop: cdp_role.)
 __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
                                                 const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
-                                                int32_t* __restrict__ status, int pending, const CdPre& pre,
-                                                double* aop_ext = nullptr, unsigned long long* stamp = nullptr)
+                                                int32_t* __restrict__ status, int pending, const CdPre& pre)
 {
-#define CD_WSTAMP(slot) do { if (stamp && threadIdx.x == 0) stamp[slot] = wall_clock64(); } while (0)
-    CD_WSTAMP(1);
     // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
     // chain stops after the last real row, L and L^-1 are the identity there
     const int r_here = min(64, max(0, 2 * sel[slot_k] - 64 * step));
@@ -1013,19 +1009,18 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     double* Lout = Linv + (long)step * 64 * 64;
     CD_STAMP(pr0);
     const d4 (&tacc)[CD_TT] = pre.tacc;
-    if (pending >= 2) {
+    if (pending == 2) {
         // Single-launch block step: the panel row of THIS block for the previous column, X = A(k,k-1) Linv(k-1)^T,
         // is formed here (nobody else needs it: the tile workgroups of the same launch recompute the S-row panels
         // they use).  Operands staged behind Lf, over members that are initialised afterwards.
-        double* Aop = (pending == 3) ? aop_ext : sh.Mf;                     // [m][CD_OPLD] : A(k,k-1)(row, m)
-        const double* Lop = (pending == 3) ? sh.Mf : sh.Mf + 64 * CD_OPLD;  // [m][ldl]     : Linv(k-1)(c, m)
-        const int ldl = (pending == 3) ? CD_LD : CD_OPLD;                   // Mf[m * CD_LD + c] = Linv(c, m): the same image
+        double* Aop = sh.Mf;                         // [m][CD_OPLD] : A(k,k-1)(row, m)
+        double* Lop = sh.Mf + 64 * CD_OPLD;          // [m][CD_OPLD] : Linv(k-1)(c, m)
         const int row = t & 63, g = t >> 6;
 #pragma unroll
         for (int q = 0; q < 64 / (CD_THREADS / 64); ++q) {
             const int m = g + (CD_THREADS / 64) * q;
             Aop[m * CD_OPLD + row] = pre.a[q];
-            if (pending == 2) sh.Mf[64 * CD_OPLD + m * CD_OPLD + row] = pre.l[q];
+            Lop[m * CD_OPLD + row] = pre.l[q];
         }
         __syncthreads();
         CD_STAMP(pr1);
@@ -1041,7 +1036,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
                 for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[(kk + lr) * CD_OPLD + 16 * tr + lc],
-                                                               Lop[(kk + lr) * ldl + 16 * tc + lc], acc, 0, 0, 0);
+                                                               Lop[(kk + lr) * CD_OPLD + 16 * tc + lc], acc, 0, 0, 0);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) sh.Lf[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
             }
@@ -1049,7 +1044,6 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         __syncthreads();
         CD_STAMP(pr2);
         CD_ACC_T(9, pr1, pr2, 0);
-        CD_WSTAMP(2);
     }
     CD_STAMP(pr3);
     {
@@ -1075,10 +1069,8 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         __syncthreads();                                             // (C)
         CD_STAMP(pr4);
         CD_ACC_T(10, pr3, pr4, 0);
-        CD_WSTAMP(3);
         if (wave == 0) cd_panel_wave(sh, n_piv4);
         else (void)cd_inverse_wave(sh, n_piv4);
-        CD_WSTAMP(4);
         CD_STAMP(pr5);
         CD_ACC_T(11, pr4, pr5, 0);
     } else {
@@ -1092,7 +1084,6 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
         }
     }
     __syncthreads();
-    CD_WSTAMP(5);
     bool bad = false;
     {
         const int i = t & 63, g = t >> 6;
@@ -1103,7 +1094,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             const double mv = (i >= done) ? ((i == c) ? 1.0 : 0.0) : sh.Mf[c * CD_LD + i];
             if (i == c && !(lv > 0.0 && lv < 1.0e300)) bad = true;      // a non-positive pivot turns the diagonal into NaN / 0 / inf
             Lout[i + 64 * c] = (i >= c) ? mv : 0.0;
-            if (i >= c && pending != 3) tile[i + (long)c * ldA] = lv;
+            if (i >= c) tile[i + (long)c * ldA] = lv;
         }
     }
     CD_STAMP(pr6);
@@ -1111,7 +1102,6 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     if (t == 0) { CD_ACC_T(13, pr0, pr0 + 1, 0); }
     if (bad) atomicMin(status, -6);                              // RSLAM_ERR_NOT_SPD
     if (t == 0 && sh.timeout) atomicMin(status, -3);             // RSLAM_ERR_HIP: hand-over protocol broke (never expected)
-#undef CD_WSTAMP
 }
 
 __global__ void __launch_bounds__(CD_THREADS)
