@@ -260,8 +260,11 @@ int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t h
 int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph);
 
 /* Diagnostics of the resident pipeline since rslam_create (any pointer may be NULL): hipGraph captures
- * (a change of the launch sequence re-captures), update stages that had to be re-run because the
- * factor sweep had been enqueued too short for the frame's inlier count. */
+ * (a change of the launch sequence re-captures); update stages that had to be re-run -- because the
+ * launch-per-step factor sweep (large systems) had been enqueued too short for the frame's inlier count, or
+ * because a hand-over of the persistent sweep ran into its bounded wait (its workgroups were not all resident:
+ * another user of the GPU), in which case the stage is re-run with the launch-per-step sweep and the context keeps
+ * to that sweep for the next 64 frames. */
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 
 /* Block until the stream is idle; returns the device-side status of the

@@ -72,6 +72,8 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
                            const double* Wsrc, const int32_t* rank_of, int32_t* sweep_flags /* SWEEP_FLAG_INTS, zeroed here; nullable */);
 constexpr int SWEEP_FLAG_INTS = 112;   // hand-over flags of the persistent factor sweep (kernels.hip SweepFlags)
 bool sweep_persistent_eligible(const SystemDims& d);
+void set_sweep_exp_mask(int mask);     // -1 = environment (RSLAM_SWEEP_EXP); diagnostics and fault injection
+int sweep_exp_mask();
 // What the persistent sweep builds its stacked system [S; P H^T; nu^T] from (it has no prepare_system pass): the
 // arguments of launch_prepare_system.  Wsrc != nullptr: P H^T columns come from the matched-feature matrix (LI pass),
 // else they are already in rows [RP, RP+NP) of A (HI pass: launch_pht wrote them there).

@@ -1918,7 +1918,9 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
     if (nblk <= 0) return;
     const int r_total = 2 * sel[slot_k];
     if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg);
-    else cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask);
+    else if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask);
+    // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
+    //  been scheduled: every strip must run into its bounded wait and the host must recover the frame)
 }
 
 // dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
@@ -1978,6 +1980,16 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nu
     return 0;
 }
 
+// RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 4 fault injection (the chain
+// workgroup does not run); set_sweep_exp_mask overrides the environment (tests)
+static int g_sweep_exp_override = -1;
+void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }
+int sweep_exp_mask()
+{
+    static const int env = getenv("RSLAM_SWEEP_EXP") ? atoi(getenv("RSLAM_SWEEP_EXP")) : 0;
+    return g_sweep_exp_override >= 0 ? g_sweep_exp_override : env;
+}
+
 bool sweep_persistent_eligible(const SystemDims& d)
 {
     static int cus = -1;
@@ -2012,7 +2024,7 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
         // one launch for the whole sweep, sized for the largest inlier count the frame can have: the launch sequence
         // never depends on the previous frame (cap_blocks is not used)
         const dim3 grid(1 + d.ldA / 16), block(CD_THREADS);
-        static const int exp_mask = getenv("RSLAM_SWEEP_EXP") ? atoi(getenv("RSLAM_SWEEP_EXP")) : 0;   // measurement switches
+        const int exp_mask = sweep_exp_mask();             // measurement / fault-injection switches
         const int set = (slot_k == SEL_K_LI) ? 0 : 1;              // the LI and the HI sweep of a frame alternate between the two flag sets
         int32_t* fl_cur = flags + set * SWEEP_FLAG_INTS;
         int32_t* fl_other = flags + (1 - set) * SWEEP_FLAG_INTS;

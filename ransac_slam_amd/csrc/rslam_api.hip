@@ -108,6 +108,10 @@ struct rslam_ctx {
     int reruns = 0;
     int graph_captures = 0;
     int last_raw_status = 0;
+    // The persistent sweep needs its whole grid resident at once.  When a bounded wait runs out (somebody else is holding
+    // CUs of this GPU) the update stage is re-run with the launch-per-step sweep, and so are the next frames for a while.
+    int steps_frames_left = 0;
+    int sweep_fallbacks = 0;
     bool sweep_can_overflow = false;   // the update stage in flight was enqueued with a shortened sweep ...
     bool frame_checked = true;         // ... and read_status has (not) looked at it yet
 };
@@ -115,6 +119,7 @@ struct rslam_ctx {
 // bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
 static bool sweep_is_persistent(const rslam_ctx* c)
 {
+    if (c->steps_frames_left > 0) return false;      // a hand-over of the persistent sweep timed out recently (see read_status)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
     return sweep_persistent_eligible(d);
 }
@@ -577,8 +582,30 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         rc = read_status_raw(c, sel);
         if (rc) return rc;
     }
+    if (sel[SEL_STATUS] <= -30 && c->last_sup && sweep_is_persistent(c)) {
+        // A bounded wait of the persistent sweep ran out: its workgroups were not all resident (another user of the GPU), not
+        // an error of the data.  Re-run the update stage with the launch-per-step sweep at full length, and keep to it for
+        // the next frames.
+        c->last_raw_status = sel[SEL_STATUS];
+        c->steps_frames_left = 64;
+        ++c->sweep_fallbacks;
+        c->cap_li = c->cap_hi = 1 << 20;
+        invalidate_graph(c);
+        const int timing = c->timing; c->timing = 0;
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_CAP_FLAG, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream));
+        rc = enqueue_update(c, c->last_sup);
+        c->timing = timing;
+        if (rc) return rc;
+        rc = read_status_raw(c, sel);
+        if (rc) return rc;
+    } else if (c->steps_frames_left > 0 && c->last_sup && !c->frame_checked) {
+        if (--c->steps_frames_left == 0) invalidate_graph(c);     // back to the persistent sweep: new launch sequence
+    }
     if (sel[SEL_STATUS_FRONT] < sel[SEL_STATUS]) sel[SEL_STATUS] = sel[SEL_STATUS_FRONT];
-    if (sel[SEL_STATUS] <= -30) {                 // a bounded wait of the persistent sweep ran out: which one is kept for diagnosis
+    if (sel[SEL_STATUS] <= -30) {                 // (still: which wait it was is kept for diagnosis)
         c->last_raw_status = sel[SEL_STATUS];
         sel[SEL_STATUS] = RSLAM_ERR_HIP;
     }
@@ -1076,7 +1103,7 @@ extern "C" int rslam_get_counters(rslam_ctx* c, int32_t* graph_captures, int32_t
 {
     if (!c) return RSLAM_ERR_ARG;
     if (graph_captures) *graph_captures = c->graph_captures;
-    if (sweep_reruns) *sweep_reruns = c->reruns;
+    if (sweep_reruns) *sweep_reruns = c->reruns + c->sweep_fallbacks;
     return RSLAM_OK;
 }
 
@@ -1357,6 +1384,8 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
 // diagnostic (not part of include/rslam.h): time stamps of the persistent factor sweep, see scripts/sweep_stamps.py
 namespace rslam { int debug_sweep_stamps(unsigned long long* out, int enable); }
 extern "C" int rslam_debug_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
+// diagnostics / fault injection (not part of include/rslam.h): RSLAM_SWEEP_EXP switches from the host, -1 = environment
+extern "C" int rslam_debug_set_sweep_exp(int mask) { rslam::set_sweep_exp_mask(mask); return RSLAM_OK; }
 
 extern "C" int rslam_debug_sweep_stamps(rslam_ctx* c, unsigned long long* out, int enable)
 {

@@ -266,6 +266,39 @@ def test_sweep_launch_sizing_overflow_reruns(hip, oracle_lib):
     g.close()
 
 
+def test_persistent_sweep_timeout_falls_back(hip, oracle_lib):
+    """The persistent factor sweep needs all its workgroups resident at once.  Fault injection (the chain workgroup does
+    not show up, as if another user of the GPU held its CU): every strip must leave through its bounded wait, the host
+    must notice, re-run the update stage with the launch-per-step sweep and return the right answer; the context keeps
+    working (on the fallback path for a while)."""
+    import ctypes as C
+    fr = make_frame(L=90, H=120, seed=321)
+    cfg = default_config(compat=0, adaptive=1)
+    o = oracle_lib.Oracle(cfg, structure=1)
+    _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z, ic, fr.draws)
+    lib = hip.lib()
+    lib.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
+    lib.rslam_debug_last_raw_status.argtypes = [C.c_void_p]
+    lib.rslam_debug_set_sweep_exp(16)
+    try:
+        g = hip.RslamHip(cfg)
+        g.predict(fr.types, fr.x_pred, fr.P_pred)
+        r1 = g.ransac_update(fr.z, ic, fr.draws)            # times out inside, recovers inside
+    finally:
+        lib.rslam_debug_set_sweep_exp(-1)
+    assert lib.rslam_debug_last_raw_status(g._h) <= -30      # a hand-over wait did run out ...
+    assert g.counters()["sweep_reruns"] >= 1                # ... and the update stage was re-run
+    assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+    assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+    # the next frame on the same context (launch-per-step sweep for a while) is right as well
+    g.predict(fr.types, fr.x_pred, fr.P_pred)
+    r2 = g.ransac_update(fr.z, ic, fr.draws)
+    assert np.array_equal(r2["li"], r0["li"]) and close_P(r2["P_new"], r0["P_new"])
+    g.close()
+
+
 def test_two_phase_graph_frame_equals_full(hip):
     """The multi-GPU frame (two replayed graphs around the exchange) on one GPU, slice = everything."""
     import torch
