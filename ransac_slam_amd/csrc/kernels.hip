@@ -1333,7 +1333,8 @@ constexpr int SW_MAX_BLOCKS = 32;
 struct SweepFlags {
     int32_t linv_ready;                 // diagonal blocks whose L^-1 is published
     int32_t xrow_ready;                 // k: the chain has published its panel blocks L(1,0) .. L(k,k-1)
-    int32_t pad[14];
+    int32_t tiles01;                    // P H^T / nu strips that have written their share of tiles (0,0), (1,0), (1,1)
+    int32_t pad[13];
     int32_t panel_cnt[SW_MAX_BLOCKS];   // [k]: S strips that have published their rows of panel k (row blocks k+2 ..)
     int32_t row_ready[SW_MAX_BLOCKS];   // [b]: strips of S row block b that have handed tiles (b,b-1), (b,b) over
     int32_t row_cnt[SW_MAX_BLOCKS];     // [b]: panel rows published by the strips of S row block b, all steps (4 per step)
@@ -1426,7 +1427,8 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     if (dbg) who = (strip == 8) ? 1 : (strip == 4 * (nblk - 1)) ? 2 : (strip == 4 * rp_blocks) ? 3 : (strip == (int)(ldA / 16) - 4) ? 4 : -1;
     if (who < 0) dbg = nullptr;
     const bool is_s = b < rp_blocks;
-    if (is_s && b >= nblk) return;                          // padding rows of S
+    // padding rows of S; row blocks 0 and 1 are the chain's first two diagonal blocks, assembled by the lower strips together
+    if (is_s && (b >= nblk || b <= 1)) return;
     if (b == (int)(ldA / 64) - 1 && (strip & 3) != 0) return;   // below nu^T there is only zero padding
     const int RP = 64 * rp_blocks;
     const int ncols = is_s ? b + 1 : nblk;                  // column blocks held
@@ -1442,6 +1444,30 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     int* abort = reinterpret_cast<int*>(lds + 2 * 64 * 16);
     bool alive = true;
     if (t == 0) *abort = 0;            // (the first wait has a barrier before anybody reads it)
+    if (!is_s) {
+        // First of all, together with the other P H^T / nu strips: the tiles the chain starts with, (0,0) and for its second
+        // diagonal block (1,0), (1,1) -- 3 x 4096 entries of S over ~NP/16 workgroups, one entry per thread, so that the chain
+        // waits for one gather + one hand-over instead of for a strip that gathers a whole 16 x 64 piece through its CU's
+        // address unit (~6 us more on the first block of every sweep).
+        const int nlow = NP / 16 + 1, p = strip - 4 * rp_blocks < nlow ? strip - 4 * rp_blocks : nlow - 1;   // (the nu strip is the last)
+        const int E = (nblk >= 2 ? 3 : 1) * 4096;
+        for (int e = (int)((long)p * E / nlow) + t; e < (int)((long)(p + 1) * E / nlow); e += CD_THREADS) {
+            const int tile = e >> 12, a = (e & 63) + (tile >= 1 ? 64 : 0), c = ((e >> 6) & 63) + (tile == 2 ? 64 : 0);
+            double Hf[13];
+            int fo = 0, fw = 0;
+            if (a < r_total) {
+                const int fa = src.list[a >> 1];
+                fo = src.off[fa]; fw = (src.type[fa] == 0) ? 13 : 10;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) Hf[k] = src.H13[26L * fa + 13 * (a & 1) + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 13; ++k) Hf[k] = 0.0;
+            }
+            st_coh(A + a + (long)c * ldA, sys_S(src, A, ldA, NP, RP, r_total, a, c, Hf, fo, fw));
+        }
+        sw_post_add(&fl->tiles01);
+    }
     // acc[jj][reg] of lane (ln, lq) = strip(ln, 64 (2 jj + g) + 16 w + lq + 4 reg); the strip assembles its rows of the
     // stacked system itself (there is no prepare_system pass in front of this kernel)
     double* base = A + 16L * strip + ln + (64L * g + 16L * w + lq) * ldA;
@@ -1477,19 +1503,6 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                 }
             }
         });
-    }
-    if (is_s && b <= 1) {
-        // Row blocks 0 and 1 go to the chain as they are assembled: tile (0,0); tiles (1,0), (1,1).  (Row block 1 has no
-        // step of its own: its panel block L(1,0) is the chain's prologue of diagonal block 1.)
-        static_for<0, (NH < 1 ? NH : 1)>([&](auto JJ) {
-            constexpr int jj = decltype(JJ)::value;
-            if (2 * jj + g <= b) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) st_coh(base + (128L * jj + 4 * reg) * ldA, acc[jj][reg]);
-            }
-        });
-        sw_post_add(&fl->row_ready[b]);
-        return;
     }
     static_for<0, NJ>([&](auto K) {
         constexpr int k = decltype(K)::value;
@@ -1609,7 +1622,8 @@ struct CdpNext {                 // what a T wave fetches for the next block
     const double* a_src;         // A(k+1,k) + lane (row)
     const double* tile;          // tile (k+1,k+1)
     long ldA;
-    const int32_t* flag;         // row_ready[k+1], nullptr = the prepared system (always there)
+    const int32_t* flag;         // hand-over counter of those tiles ...
+    int need;                    // ... and the count that says they are all there
     double* Aop; double* Tpre;
 };
 
@@ -1666,7 +1680,7 @@ __device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, doub
     if (st != 4) {
         if (nx.flag && st != 7) {
             int spins = 0;
-            while (ld_flag(nx.flag) < 4) {
+            while (ld_flag(nx.flag) < nx.need) {
                 if (++spins > SW_SPIN_LIMIT) { sh.timeout = 5; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -1755,12 +1769,12 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             if (want_next) {
                 if (sb == 1 && q == 0) fv = nx.flag ? ld_flag(nx.flag) : 4;     // consumed four steps later: its latency is hidden
                 if (sb == 2) {
-                    if (q == 0 && fv >= 4) { st = 1; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
+                    if (q == 0 && fv >= nx.need) { st = 1; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
                     if (q == 1 && st == 0) fv = ld_flag(nx.flag);            // second look, consumed at step 12
                     if (st == 1) cdp_issue_q<B>(q, nx, pf);
                     if (q == 3 && st == 1) st = 2;
                 } else if (sb == 3) {
-                    if (q == 0 && st == 0 && fv >= 4) { st = 5; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
+                    if (q == 0 && st == 0 && fv >= nx.need) { st = 5; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
                     if (q == 1 && st == 0) { fv = ld_flag(nx.flag); st = 6; }     // third look, consumed at the top of the next block
                     if (st == 2) cdp_store_q<B>(q, nx, pf);
                     else if (st == 5) cdp_issue_q<B>(q, nx, pf);
@@ -1769,7 +1783,7 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             }
         }
     }
-    return (st == 6 && fv >= 4) ? 7 : st;       // 7: not fetched, but the hand-over has been seen: no polling needed
+    return (st == 6 && fv >= nx.need) ? 7 : st;       // 7: not fetched, but the hand-over has been seen: no polling needed
 }
 
 // One wave role of the chain workgroup over all diagonal blocks.  ROLE: 0 panel wave, 1 inverse wave, 2..5 T waves,
@@ -1777,7 +1791,7 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
 // from block to block (the T waves' fetch registers) does not count against the registers of the others.
 template <int ROLE>
 __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int nblk, int r_total, double* Linv, double* Ypanel,
-                                         SweepFlags* fl, int32_t* status, unsigned long long* dbg, int exp_mask)
+                                         SweepFlags* fl, int32_t* status, unsigned long long* dbg, int exp_mask, int n_lower_strips)
 {
     CdShared& sh = *reinterpret_cast<CdShared*>(lds);
     double* Aop = lds + CDP_OFF_AOP;
@@ -1808,7 +1822,8 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             CdpNext cur;
             cur.a_src = A + (long)k * 64 + row + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
             cur.tile = A + (long)k * 64 + (long)k * 64 * ldA;
-            cur.ldA = ldA; cur.flag = &fl->row_ready[k]; cur.Aop = Aop; cur.Tpre = Tpre;
+            cur.ldA = ldA; cur.Aop = Aop; cur.Tpre = Tpre;
+            cur.flag = k <= 1 ? &fl->tiles01 : &fl->row_ready[k]; cur.need = k <= 1 ? n_lower_strips : 4;
             cdp_finish<TB>(cur, sh, pf, fetch_st);
         }
         __syncthreads();                                  // inputs of block k are in LDS
@@ -1859,7 +1874,8 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             CdpNext nx;
             nx.a_src = A + (long)(k + 1) * 64 + row + (long)k * 64 * ldA;
             nx.tile = A + (long)(k + 1) * 64 + (long)(k + 1) * 64 * ldA;
-            nx.ldA = ldA; nx.flag = &fl->row_ready[k + 1]; nx.Aop = Aop; nx.Tpre = Tpre;
+            nx.ldA = ldA; nx.Aop = Aop; nx.Tpre = Tpre;
+            nx.flag = k + 1 <= 1 ? &fl->tiles01 : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4;
             fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, nx, want_next, pf, stamp, exp_mask);
         } else {
             cd_m_wave<ROLE - 2 - CD_TW>(sh, n_piv4, 0);
@@ -1885,20 +1901,20 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
 }
 
 __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long ldA, int nblk, int r_total, double* Linv, double* Ypanel,
-                                                    SweepFlags* fl, int32_t* status, unsigned long long* dbg, int exp_mask)
+                                                    SweepFlags* fl, int32_t* status, unsigned long long* dbg, int exp_mask, int n_lower_strips)
 {
     CdShared& sh = *reinterpret_cast<CdShared*>(lds);
     if (threadIdx.x == 0) sh.timeout = 0;
     __syncthreads();
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: cdp_role<0>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    case 1: cdp_role<1>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    case 2: cdp_role<2>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    case 3: cdp_role<3>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    case 4: cdp_role<4>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    case 5: cdp_role<5>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    case 6: cdp_role<6>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
-    default: cdp_role<7>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask); break;
+    case 0: cdp_role<0>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    case 1: cdp_role<1>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    case 2: cdp_role<2>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    case 3: cdp_role<3>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    case 4: cdp_role<4>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    case 5: cdp_role<5>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    case 6: cdp_role<6>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    default: cdp_role<7>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
     }
 }
 
@@ -1918,7 +1934,7 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
     if (nblk <= 0) return;
     const int r_total = 2 * sel[slot_k];
     if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg);
-    else if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask);
+    else if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, NP / 16 + 1);
     // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
     //  been scheduled: every strip must run into its bounded wait and the host must recover the frame)
 }
