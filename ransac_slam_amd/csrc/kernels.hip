@@ -932,11 +932,14 @@ __device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
             if (s > 1) {
                 const double* Xq = sh.Xs[(q + 2) & 3];       // panel s-2
                 const double* Mq = sh.Ms[q & 1];             // Ms of block s-2
+                // (rows of the inverse above the pivot block are final: a tile whose rows all are -- 16 tr + 15 <= 4 (s-2) + 3 --
+                //  gets no more updates)
 #pragma unroll
                 for (int o = 0; o < NT; ++o) {
                     const int idx = C + CD_MW * o;
-                    acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xq[lr * 64 + 16 * cd_tr(idx) + lc], -Mq[lr * 64 + 16 * cd_tc(idx) + lc],
-                                                                  acc[o], 0, 0, 0);          // M -= X (L4^-1 M(p,:))
+                    if (sb <= cd_tr(idx) || (sb == cd_tr(idx) + 1 && q == 0))
+                        acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xq[lr * 64 + 16 * cd_tr(idx) + lc], -Mq[lr * 64 + 16 * cd_tc(idx) + lc],
+                                                                      acc[o], 0, 0, 0);          // M -= X (L4^-1 M(p,:))
                 }
             }
             // strip of block s (updates <= s-2 applied): rows p0 + lr of a tile in block row b0 = register q
@@ -1742,8 +1745,10 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
                     a[o] = Xp[lr * 64 + 16 * cd_tr(B + CD_TW * o) + lc];
                     b[o] = Xp[lr * 64 + 16 * cd_tc(B + CD_TW * o) + lc];
                 }
+                // (a tile whose 16 columns have all been eliminated -- tile column < sb -- is never read again: no update)
 #pragma unroll
-                for (int o = 0; o < NT; ++o) acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);   // T -= X X^T
+                for (int o = 0; o < NT; ++o)
+                    if (cd_tc(B + CD_TW * o) >= sb) acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);   // T -= X X^T
             }
             // strip of block s+1 (updates <= s-1 applied)
             if (p0 + 4 < 64) {
