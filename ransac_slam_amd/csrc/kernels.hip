@@ -1377,6 +1377,23 @@ __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* 
     return *abort == 0;
 }
 
+// Two flags at once (one memory round trip instead of two when both are already up, as they usually are): returns when
+// *fa >= na and *fb >= nb.
+__device__ __forceinline__ bool sw_wait2(const int32_t* fa, int na, const int32_t* fb, int nb, int32_t* status, int* abort, int code)
+{
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (true) {
+            const int a = ld_flag(fa), b = ld_flag(fb);
+            if (a >= na && b >= nb) break;
+            if (++spins > SW_SPIN_LIMIT) { atomicMin(status, -(30 + code)); *abort = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    return *abort == 0;
+}
+
 // all threads: the coherent stores of this workgroup have reached memory, then *flag += 1
 __device__ __forceinline__ void sw_post_add(int32_t* flag)
 {
@@ -1553,10 +1570,10 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                 // panel blocks L(j,k): j = k+1 from the chain, j >= k+2 from the strips of S row block j.  The step that
                 // ends with the hand-over to the chain (S rows, k = b-2) only needs j = b-1 = k+1 and j = b, its own
                 // row block: it waits for its three siblings, not for every S strip
-                if (alive) alive = sw_wait(&fl->xrow_ready, k + 1, status, abort, 2);
                 if (alive) {
-                    if (is_s && k == b - 2) alive = sw_wait(&fl->row_cnt[b], 4 * (k + 1), status, abort, 3);
-                    else if (k + 2 < nblk) alive = sw_wait(&fl->panel_cnt[k], 4 * (nblk - 2 - k), status, abort, 4);
+                    if (is_s && k == b - 2) alive = sw_wait2(&fl->xrow_ready, k + 1, &fl->row_cnt[b], 4 * (k + 1), status, abort, 3);
+                    else if (k + 2 < nblk) alive = sw_wait2(&fl->xrow_ready, k + 1, &fl->panel_cnt[k], 4 * (nblk - 2 - k), status, abort, 4);
+                    else alive = sw_wait(&fl->xrow_ready, k + 1, status, abort, 2);
                 }
                 sw_stamp(dbg, who, k, 3);
                 // column blocks j = 2 jj + g, k < j < ncols: a contiguous jj range whose lower end is known at compile
