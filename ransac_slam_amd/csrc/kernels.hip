@@ -2251,7 +2251,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         if (xu.groups > 0) {                        // Jnorm comes from group 0 of this launch
             int spins = 0;
             while (__hip_atomic_load(xu.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < xu.token) {
-                if (++spins > (1 << 22)) { atomicMin(const_cast<int32_t*>(sel) + SEL_STATUS, -3); break; }
+                if (++spins > (1 << 22)) { atomicMin(xu.flag + (SEL_STATUS - SEL_XU_FLAG), -39); break; }   // (xu.flag = sel + SEL_XU_FLAG)
                 __builtin_amdgcn_s_sleep(2);
             }
         }

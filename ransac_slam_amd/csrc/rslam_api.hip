@@ -145,7 +145,7 @@ static void invalidate_graph(rslam_ctx* c)
 
 extern "C" int rslam_destroy(rslam_ctx* c);
 
-extern "C" const char* rslam_version(void) { return "rslam-hip 0.1 (gfx950)"; }
+extern "C" const char* rslam_version(void) { return "rslam-hip 0.2 (gfx950)"; }
 
 extern "C" const char* rslam_error_string(int code)
 {
