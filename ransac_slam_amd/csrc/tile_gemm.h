@@ -237,25 +237,49 @@ constexpr int TD_LDS_DOUBLES = 4 * TD_OPER_DOUBLES;       // A, B x 2 buffers = 
 typedef __attribute__((address_space(3))) void tg_lds_void;
 typedef __attribute__((address_space(1))) const void tg_glb_void;
 
+// Per-lane part of a DMA source address (bytes): rows (2 (lane & 31), +1) of k-row 2 (lane >> 5) -- loop invariant, so
+// the address of a segment is a wave-uniform 64-bit base (SALU) plus this 32-bit VGPR offset: the `saddr` form of
+// global_load_lds, no VALU per transfer.  (The first version rebuilt the 64-bit per-lane address with a quarter-rate
+// 64-bit multiply for each of the 8 transfers of a chunk: ~15 % of the loop, scripts/probes/gemm_loop.hip.)
+__device__ __forceinline__ unsigned td_lane_offset(long ld)
+{
+    const int lane = threadIdx.x & 63;
+    return (unsigned)((2 * (lane & 31) + 2 * (lane >> 5) * ld) * (long)sizeof(double));
+}
+
+// segment sg (k-step sg >> 1, parity sg & 1) of the chunk that starts at column k0, both operands
+__device__ __forceinline__ void td_issue_seg(const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
+                                             int k0, int sg, double* As, double* Bs)
+{
+    const long ku = k0 + 4 * (sg >> 1) + (sg & 1);        // wave-uniform
+    const char* ga = reinterpret_cast<const char*>(A + ku * lda) + la;
+    const char* gb = reinterpret_cast<const char*>(B + ku * ldb) + lb;
+    __builtin_amdgcn_global_load_lds((tg_glb_void*)ga, (tg_lds_void*)(As + sg * TD_SEG), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((tg_glb_void*)gb, (tg_lds_void*)(Bs + sg * TD_SEG), 16, 0, 0);
+}
+
 // chunk k0 .. k0 + TG_KC of both operands -> LDS images As, Bs; four segments per wave and operand
 __device__ __forceinline__ void td_issue_chunk(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                int k0, double* As, double* Bs)
 {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = 2 * (lane & 31), up = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned la = td_lane_offset(lda), lb = td_lane_offset(ldb);
 #pragma unroll
-    for (int q = 0; q < TG_KC / 8; ++q) {
-        const int sg = wave + 4 * q;                      // segment: k-step sg >> 1, parity sg & 1
-        const long k = k0 + 4 * (sg >> 1) + (sg & 1) + 2 * up;
-        __builtin_amdgcn_global_load_lds((tg_glb_void*)(A + r + k * lda), (tg_lds_void*)(As + sg * TD_SEG), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((tg_glb_void*)(B + r + k * ldb), (tg_lds_void*)(Bs + sg * TD_SEG), 16, 0, 0);
-    }
+    for (int q = 0; q < TG_KC / 8; ++q) td_issue_seg(A, lda, la, B, ldb, lb, k0, wave + 4 * q, As, Bs);
 }
 
-__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc)
+// One staged chunk: 8 k-steps of 16 MFMAs.  The fragments of k-step s+1 are read while the MFMAs of k-step s run, and
+// the instruction order is pinned (sched_group_barrier): one LDS read after every second MFMA.  Left to itself the
+// compiler issues the 16 reads of two k-steps in one burst and waits for all of them, which starves the matrix pipe
+// (probe: 57 -> 68.8 TFLOP/s for the loop without staging, = the bare MFMA rate).  When `next` is set, the wave's four
+// segment pairs of the NEXT chunk are issued one per k-step instead of in a burst at the top of the chunk.
+template <bool NEXT>
+__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc,
+                                                 const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
+                                                 int k0n, double* An, double* Bn)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / TG_WN, wn = wave % TG_WN;
     const int kq = lane >> 4, ij = lane & 15;
     const int koff = (kq & 1) * TD_SEG + (kq >> 1) * 64;
@@ -275,6 +299,8 @@ __device__ __forceinline__ void td_compute_chunk(const double* As, const double*
     for (int kk = 0; kk < TG_KC; kk += 4) {
         double na[TG_MI];
         BFrag nb[TG_NI];
+        const bool dma = NEXT && (kk / 4 < TG_KC / 8);
+        if (dma) td_issue_seg(A, lda, la, B, ldb, lb, k0n, wave + 4 * (kk / 4), An, Bn);
         if (kk + 4 < TG_KC) {
             const int o = (kk / 4 + 1) * TD_STEP;
 #pragma unroll
@@ -286,6 +312,17 @@ __device__ __forceinline__ void td_compute_chunk(const double* As, const double*
         for (int mi = 0; mi < TG_MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TG_NI; ++ni) tg_mma_16x16x4(a[mi], b[ni], acc[mi][ni]);
+        if (dma) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // the two transfers first
+        if (kk + 4 < TG_KC) {
+#pragma unroll
+            for (int i = 0; i < 4 * TG_MI * TG_NI / 2; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read
+            }
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TG_MI * TG_NI, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // nothing crosses a k-step: the reads stay one step ahead of their use
         if (kk + 4 < TG_KC) {
 #pragma unroll
             for (int mi = 0; mi < TG_MI; ++mi) a[mi] = na[mi];
@@ -305,14 +342,18 @@ __device__ __forceinline__ void tile_gemm_nt_dma(const double* __restrict__ A, l
     double* Bs1 = lds + 3 * TD_OPER_DOUBLES;
     const int nchunks = K / TG_KC;
     if (nchunks <= 0) return;
+    const unsigned la = td_lane_offset(lda), lb = td_lane_offset(ldb);
     td_issue_chunk(A, lda, B, ldb, 0, As0, Bs0);
     __syncthreads();                                      // (a barrier waits for this wave's DMA: vmcnt(0))
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = 0; c + 1 < nchunks; ++c) {
         // chunk c+1 flies into the other buffer (everybody left it at the last barrier) under the MFMAs of chunk c
-        if (c + 1 < nchunks) { if (c & 1) td_issue_chunk(A, lda, B, ldb, (c + 1) * TG_KC, As0, Bs0); else td_issue_chunk(A, lda, B, ldb, (c + 1) * TG_KC, As1, Bs1); }
-        if (c & 1) td_compute_chunk(As1, Bs1, acc); else td_compute_chunk(As0, Bs0, acc);
+        if (c & 1) td_compute_chunk<true>(As1, Bs1, acc, A, lda, la, B, ldb, lb, (c + 1) * TG_KC, As0, Bs0);
+        else       td_compute_chunk<true>(As0, Bs0, acc, A, lda, la, B, ldb, lb, (c + 1) * TG_KC, As1, Bs1);
         __syncthreads();
     }
+    if ((nchunks - 1) & 1) td_compute_chunk<false>(As1, Bs1, acc, A, lda, la, B, ldb, lb, 0, As0, Bs0);
+    else                   td_compute_chunk<false>(As0, Bs0, acc, A, lda, la, B, ldb, lb, 0, As1, Bs1);
+    __syncthreads();
 }
 
 __device__ __forceinline__ void tg_zero(TgAcc& acc)
