@@ -2217,30 +2217,34 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         }
         return;
     }
+    // The HI pass reads what the LI pass wrote: mirrored tile pairs, i.e. exactly symmetric off the diagonal tiles, so
+    // 1/2 (P + P^T) = P there bit for bit and the mirror tile need not be read (a quarter of this pass's reads).  Not
+    // when the LI pass was a pass-through (no inliers: its output is the prior as uploaded).
+    const bool mirror_known = (xu.token == 2) && (bi != bj) && (sel[SEL_NBLK_LI] > 0);
+    // Both P tiles are requested before the K loop and land under it: the epilogue is left with the stores only.
+    double pij[16], pji[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        pij[q] = Pij[row + (long)c * ldp];
+        pji[q] = mirror_known ? 0.0 : Pji[row + (long)c * ldp];
+    }
     TgAcc acc;
     tg_zero(acc);
     tile_gemm_nt_dma(Y + (long)bi * 64, ldy, Y + (long)bj * 64, ldy, K, lds, acc);
     double* Cs = lds;
     double* Ts = lds + TS_DOUBLES;
     tg_acc_to_lds(acc, Cs, 1.0);
-    // The HI pass reads what the LI pass wrote: mirrored tile pairs, i.e. exactly symmetric off the diagonal tiles, so
-    // 1/2 (P + P^T) = P there bit for bit and the mirror tile need not be read (a quarter of this pass's reads).  Not
-    // when the LI pass was a pass-through (no inliers: its output is the prior as uploaded).
-    const bool mirror_known = (xu.token == 2) && (bi != bj) && (sel[SEL_NBLK_LI] > 0);
     if (!mirror_known) {
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {                  // tile (bj,bi), element (row, c) -> Ts[c][row]
-            const int c = g + 4 * q;
-            Ts[c * TS_LD + row] = Pji[row + (long)c * ldp];
-        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ts[(g + 4 * q) * TS_LD + row] = pji[q];       // tile (bj,bi), element (row, c) -> Ts[c][row]
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = g + 4 * q;
-        const double pij = Pij[row + (long)c * ldp];
-        const double pji = mirror_known ? pij : Ts[row * TS_LD + c];     // P(bj,bi)[c, row]
-        const double o = (0.5 * pij + 0.5 * pji) - Cs[c * TS_LD + row];
+        const double pm = mirror_known ? pij[q] : Ts[row * TS_LD + c];           // P(bj,bi)[c, row]
+        const double o = (0.5 * pij[q] + 0.5 * pm) - Cs[c * TS_LD + row];
         Cij[row + (long)c * ldo] = o;
         Cs[c * TS_LD + row] = o;
     }
