@@ -268,52 +268,62 @@ __device__ __forceinline__ void td_issue_chunk(const double* __restrict__ A, lon
     for (int q = 0; q < TG_KC / 8; ++q) td_issue_seg(A, lda, la, B, ldb, lb, k0, wave + 4 * q, As, Bs);
 }
 
-// One staged chunk: 8 k-steps of 16 MFMAs.  The fragments of k-step s+1 are read while the MFMAs of k-step s run, and
-// the instruction order is pinned (sched_group_barrier): one LDS read after every second MFMA.  Left to itself the
-// compiler issues the 16 reads of two k-steps in one burst and waits for all of them, which starves the matrix pipe
-// (probe: 57 -> 68.8 TFLOP/s for the loop without staging, = the bare MFMA rate).  When `next` is set, the wave's four
-// segment pairs of the NEXT chunk are issued one per k-step instead of in a burst at the top of the chunk.
-template <bool NEXT>
-__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc,
-                                                 const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
-                                                 int k0n, double* An, double* Bn)
+// Fragment read addresses of a wave inside an operand image (k-step 0; k-step s is TD_STEP * s further)
+struct TdFragPtr { const double* a; const double* b0; const double* b1; const double* b2; const double* b3; };
+__device__ __forceinline__ TdFragPtr td_frag_ptr(const double* As, const double* Bs)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / TG_WN, wn = wave % TG_WN;
     const int kq = lane >> 4, ij = lane & 15;
     const int koff = (kq & 1) * TD_SEG + (kq >> 1) * 64;
-    const double* ap = As + koff + wm * 16 * TG_MI + ij;
     const double* bb = Bs + koff + wn * 16 * TG_NI;
-    const double* bp0 = bb + ij;
-    const double* bp1 = bb + ((ij - 4) & 15);
-    const double* bp2 = bb + ((ij - 8) & 15);
-    const double* bp3 = bb + ((ij - 12) & 15);
-    double a[TG_MI];
-    BFrag b[TG_NI];
+    return TdFragPtr{ As + koff + wm * 16 * TG_MI + ij, bb + ij, bb + ((ij - 4) & 15), bb + ((ij - 8) & 15), bb + ((ij - 12) & 15) };
+}
+__device__ __forceinline__ void td_read_frags(const TdFragPtr& p, int o, double (&a)[TG_MI], BFrag (&b)[TG_NI])
+{
 #pragma unroll
-    for (int mi = 0; mi < TG_MI; ++mi) a[mi] = ap[16 * mi];
+    for (int mi = 0; mi < TG_MI; ++mi) a[mi] = p.a[o + 16 * mi];
 #pragma unroll
-    for (int ni = 0; ni < TG_NI; ++ni) b[ni] = BFrag{ bp0[16 * ni], bp1[16 * ni], bp2[16 * ni], bp3[16 * ni] };
+    for (int ni = 0; ni < TG_NI; ++ni) b[ni] = BFrag{ p.b0[o + 16 * ni], p.b1[o + 16 * ni], p.b2[o + 16 * ni], p.b3[o + 16 * ni] };
+}
+
+// One staged chunk: 8 k-steps of 16 MFMAs; on entry (a, b) hold the fragments of its k-step 0.
+//  * The fragments of k-step s+1 are read while the MFMAs of k-step s run, and the instruction order is pinned
+//    (sched_group_barrier: one LDS read after every second MFMA; sched_barrier between k-steps).  Left to itself the
+//    compiler sinks the reads to their uses or issues the 16 reads of two k-steps in one burst and waits for all of
+//    them, which starves the matrix pipe (probe: 57 -> 68.8 TFLOP/s for the loop without staging = the bare MFMA rate).
+//  * NEXT: the wave's four segment pairs of the next chunk are issued one per k-step instead of in a burst, and the
+//    chunk barrier sits BEFORE the MFMAs of the last k-step: the first fragments of the next chunk are read under them,
+//    so no wave starts a chunk with an exposed LDS round trip.  (The other buffer is free again when every wave has
+//    passed that barrier: its last reads were waited for in front of it.)
+template <bool NEXT>
+__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc, double (&a)[TG_MI], BFrag (&b)[TG_NI],
+                                                 const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
+                                                 int k0n, double* An, double* Bn)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TdFragPtr cur = td_frag_ptr(As, Bs);
 #pragma unroll
     for (int kk = 0; kk < TG_KC; kk += 4) {
         double na[TG_MI];
         BFrag nb[TG_NI];
         const bool dma = NEXT && (kk / 4 < TG_KC / 8);
+        const bool last = (kk + 4 >= TG_KC);
         if (dma) td_issue_seg(A, lda, la, B, ldb, lb, k0n, wave + 4 * (kk / 4), An, Bn);
-        if (kk + 4 < TG_KC) {
-            const int o = (kk / 4 + 1) * TD_STEP;
-#pragma unroll
-            for (int mi = 0; mi < TG_MI; ++mi) na[mi] = ap[o + 16 * mi];
-#pragma unroll
-            for (int ni = 0; ni < TG_NI; ++ni) nb[ni] = BFrag{ bp0[o + 16 * ni], bp1[o + 16 * ni], bp2[o + 16 * ni], bp3[o + 16 * ni] };
+        if (!last) {
+            td_read_frags(cur, (kk / 4 + 1) * TD_STEP, na, nb);
+        } else if (NEXT) {
+            __syncthreads();                                // next chunk landed (vmcnt(0) in front of the barrier), this one read
+            __builtin_amdgcn_sched_barrier(0);
+            td_read_frags(td_frag_ptr(An, Bn), 0, na, nb);
         }
 #pragma unroll
         for (int mi = 0; mi < TG_MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TG_NI; ++ni) tg_mma_16x16x4(a[mi], b[ni], acc[mi][ni]);
-        if (dma) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // the two transfers first
-        if (kk + 4 < TG_KC) {
+        if (dma) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // the two transfers
+        if (!last || NEXT) {
 #pragma unroll
             for (int i = 0; i < 4 * TG_MI * TG_NI / 2; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // 2 MFMA
@@ -323,7 +333,7 @@ __device__ __forceinline__ void td_compute_chunk(const double* As, const double*
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TG_MI * TG_NI, 0);
         }
         __builtin_amdgcn_sched_barrier(0);                  // nothing crosses a k-step: the reads stay one step ahead of their use
-        if (kk + 4 < TG_KC) {
+        if (!last || NEXT) {
 #pragma unroll
             for (int mi = 0; mi < TG_MI; ++mi) a[mi] = na[mi];
 #pragma unroll
@@ -345,14 +355,16 @@ __device__ __forceinline__ void tile_gemm_nt_dma(const double* __restrict__ A, l
     const unsigned la = td_lane_offset(lda), lb = td_lane_offset(ldb);
     td_issue_chunk(A, lda, B, ldb, 0, As0, Bs0);
     __syncthreads();                                      // (a barrier waits for this wave's DMA: vmcnt(0))
+    double a[TG_MI];
+    BFrag b[TG_NI];
+    td_read_frags(td_frag_ptr(As0, Bs0), 0, a, b);
     for (int c = 0; c + 1 < nchunks; ++c) {
-        // chunk c+1 flies into the other buffer (everybody left it at the last barrier) under the MFMAs of chunk c
-        if (c & 1) td_compute_chunk<true>(As1, Bs1, acc, A, lda, la, B, ldb, lb, (c + 1) * TG_KC, As0, Bs0);
-        else       td_compute_chunk<true>(As0, Bs0, acc, A, lda, la, B, ldb, lb, (c + 1) * TG_KC, As1, Bs1);
-        __syncthreads();
+        // chunk c+1 flies into the other buffer under the MFMAs of chunk c
+        if (c & 1) td_compute_chunk<true>(As1, Bs1, acc, a, b, A, lda, la, B, ldb, lb, (c + 1) * TG_KC, As0, Bs0);
+        else       td_compute_chunk<true>(As0, Bs0, acc, a, b, A, lda, la, B, ldb, lb, (c + 1) * TG_KC, As1, Bs1);
     }
-    if ((nchunks - 1) & 1) td_compute_chunk<false>(As1, Bs1, acc, A, lda, la, B, ldb, lb, 0, As0, Bs0);
-    else                   td_compute_chunk<false>(As0, Bs0, acc, A, lda, la, B, ldb, lb, 0, As1, Bs1);
+    if ((nchunks - 1) & 1) td_compute_chunk<false>(As1, Bs1, acc, a, b, A, lda, la, B, ldb, lb, 0, As0, Bs0);
+    else                   td_compute_chunk<false>(As0, Bs0, acc, a, b, A, lda, la, B, ldb, lb, 0, As1, Bs1);
     __syncthreads();
 }
 
