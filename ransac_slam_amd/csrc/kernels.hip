@@ -998,6 +998,10 @@ __device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict_
 // pending: 0 nothing; 1 lookahead (the panel X = A(k,k-1) is in global memory, T -= X X^T is applied here);
 //          2 single-launch block step (X is formed here from A(k,k-1) and L^-1(k-1), both preloaded from global memory).
 // (The persistent sweep has its own block loop: cdp_role.)
+// LOCAL: nothing is read from or written to global memory: the block comes in `pre.tacc`, and L^-1 is left complete in
+//          sh.Mf (zero above the diagonal, identity beyond the rows that exist) behind a barrier (single-block systems,
+//          factored redundantly by every strip workgroup of the persistent sweep; pending must be 0).
+template <bool LOCAL = false>
 __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
                                                 const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
                                                 int32_t* __restrict__ status, int pending, const CdPre& pre)
@@ -1008,8 +1012,8 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
     const int n_piv4 = (r_here + 3) >> 2;
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    double* tile = A + (long)step * 64 + (long)step * 64 * ldA;
-    double* Lout = Linv + (long)step * 64 * 64;
+    double* tile = LOCAL ? nullptr : A + (long)step * 64 + (long)step * 64 * ldA;
+    double* Lout = LOCAL ? nullptr : Linv + (long)step * 64 * 64;
     CD_STAMP(pr0);
     const d4 (&tacc)[CD_TT] = pre.tacc;
     if (pending == 2) {
@@ -1096,10 +1100,15 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             const double lv = pad ? ((i == c) ? 1.0 : 0.0) : sh.Lf[c * CD_LD + i];
             const double mv = (i >= done) ? ((i == c) ? 1.0 : 0.0) : sh.Mf[c * CD_LD + i];
             if (i == c && !(lv > 0.0 && lv < 1.0e300)) bad = true;      // a non-positive pivot turns the diagonal into NaN / 0 / inf
-            Lout[i + 64 * c] = (i >= c) ? mv : 0.0;
-            if (i >= c) tile[i + (long)c * ldA] = lv;
+            if constexpr (LOCAL) {
+                sh.Mf[c * CD_LD + i] = (i >= c) ? mv : 0.0;
+            } else {
+                Lout[i + 64 * c] = (i >= c) ? mv : 0.0;
+                if (i >= c) tile[i + (long)c * ldA] = lv;
+            }
         }
     }
+    if constexpr (LOCAL) __syncthreads();
     CD_STAMP(pr6);
     CD_ACC_T(12, pr0, pr6, 0);
     if (t == 0) { CD_ACC_T(13, pr0, pr0 + 1, 0); }
@@ -1402,6 +1411,13 @@ __device__ __forceinline__ void sw_post_add(int32_t* flag)
     if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// LDS of the persistent sweep: the chain workgroup's staging areas behind CdShared (see cdp_role)
+constexpr int CDP_AOP_DOUBLES = 64 * CD_OPLD;          // A(k,k-1): [m][CD_OPLD]
+constexpr int CDP_TPRE_DOUBLES = 40 * 64;              // tile (k,k): lower 16 x 16 tiles in accumulator layout [(idx, reg)][lane]
+constexpr size_t CDP_OFF_AOP = (sizeof(CdShared) + 15) / 16 * 2;     // in doubles
+constexpr size_t SWP_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
+
+
 // compile-time loop: the accumulator array of a strip must never be indexed dynamically (it would move to scratch)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -1439,7 +1455,8 @@ __device__ __forceinline__ double sys_S(const SysSrc& s, const double* A, long l
 template <int NJ>
 __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, int nblk, int strip, int r_total, int NP,
                                             const SysSrc& src, const double* Linv, double* Ypanel, SweepFlags* fl,
-                                            int32_t* status, double* lds, unsigned long long* dbg)
+                                            int32_t* status, double* lds, unsigned long long* dbg,
+                                            bool single, const int32_t* sel, int slot_k)
 {
     constexpr int NH = (NJ + 1) / 2;                        // column blocks per group
     const int b = strip >> 2;                               // 64-row block of the strip
@@ -1464,7 +1481,7 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     int* abort = reinterpret_cast<int*>(lds + 2 * 64 * 16);
     bool alive = true;
     if (t == 0) *abort = 0;            // (the first wait has a barrier before anybody reads it)
-    if (!is_s) {
+    if (!is_s && !single) {
         // First of all, together with the other P H^T / nu strips: the tiles the chain starts with, (0,0) and for its second
         // diagonal block (1,0), (1,1) -- 3 x 4096 entries of S over ~NP/16 workgroups, one entry per thread, so that the chain
         // waits for one gather + one hand-over instead of for a strip that gathers a whole 16 x 64 piece through its CU's
@@ -1523,6 +1540,59 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                 }
             }
         });
+    }
+    if (single) {
+        // A system of one diagonal block (r <= 64: every LI update of the reference-faithful mode, where the consensus set
+        // is the hypothesis' own feature): nothing crosses workgroups.  Every P H^T / nu strip assembles S itself (r^2
+        // entries), factors it in its own LDS with the eight-wave pipeline of the chain workgroup -- the pivot chain stops
+        // after r pivots -- and solves its rows: no hand-over hop (~3 us each) in either direction and no chain workgroup.
+        // Same arithmetic as the shared route (lower triangle of S authoritative, same factor code): bit-identical Y.
+        CdShared& sh = *reinterpret_cast<CdShared*>(lds);
+        CdPre pre;
+#pragma unroll
+        for (int o = 0; o < CD_TT; ++o) pre.tacc[o] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (wv >= 2 && wv < 2 + CD_TW) {
+            const int lr = l >> 4, lc = l & 15;
+#pragma unroll
+            for (int o = 0; o < CD_TT; ++o) {
+                const int idx = (wv - 2) + CD_TW * o;
+                if (idx >= 10) continue;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * cd_tr(idx) + lr + 4 * reg, col = 16 * cd_tc(idx) + lc;
+                    const int a = row >= col ? row : col, c = row >= col ? col : row;
+                    double v = (a == c) ? 1.0 : 0.0;
+                    if (a < r_total) {
+                        const int fa = src.list[a >> 1];
+                        const int fo = src.off[fa], fw = (src.type[fa] == 0) ? 13 : 10;
+                        const double* hf = src.H13 + 26L * fa + 13 * (a & 1);
+                        const double* wc = sys_wcol(src, A, ldA, NP, RP, c);
+                        double sacc = 0;
+#pragma unroll
+                        for (int k = 0; k < 13; ++k) if (k < fw) sacc += hf[k] * wc[col_index(fo, k)];
+                        v += sacc;
+                    }
+                    pre.tacc[o][reg] = v;
+                }
+            }
+        }
+        cd_factor_block<true>(sh, nullptr, ldA, 0, sel, slot_k, nullptr, status, 0, pre);
+        double* Sk1 = lds + CDP_OFF_AOP;                     // behind CdShared
+        if (g == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Sk1[(16 * w + lq + 4 * reg) * 16 + ln] = acc[0][reg];
+        }
+        __syncthreads();
+        if (g == 0) {
+            d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < 4 * (w + 1)) x = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.Mf[(4 * q + lq) * CD_LD + 16 * w + ln], Sk1[(4 * q + lq) * 16 + ln], x, 0, 0, 0);
+            double* dst = Ypanel + 16L * strip + ln + (16L * w + lq) * ldA;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dst[(4L * reg) * ldA] = x[reg];
+        }
+        return;
     }
     static_for<0, NJ>([&](auto K) {
         constexpr int k = decltype(K)::value;
@@ -1633,11 +1703,6 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
 //     tile column c is first read at pivot 16 c);
 //   * L^-1(k-1) is written to global memory right after the chain ends and its flag goes out after the X product;
 //   * L itself is not kept: nobody reads it.
-constexpr int CDP_AOP_DOUBLES = 64 * CD_OPLD;          // A(k,k-1): [m][CD_OPLD]
-constexpr int CDP_TPRE_DOUBLES = 40 * 64;              // tile (k,k): lower 16 x 16 tiles in accumulator layout [(idx, reg)][lane]
-constexpr size_t CDP_OFF_AOP = (sizeof(CdShared) + 15) / 16 * 2;     // in doubles
-constexpr size_t SWP_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
-
 struct CdpNext {                 // what a T wave fetches for the next block
     const double* a_src;         // A(k+1,k) + lane (row)
     const double* tile;          // tile (k+1,k+1)
@@ -1955,7 +2020,9 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
     if (nblk > rp_blocks) nblk = rp_blocks;
     if (nblk <= 0) return;
     const int r_total = 2 * sel[slot_k];
-    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg);
+    const bool single = (nblk == 1) && !(exp_mask & 4);       // one diagonal block: every strip factors it itself, no chain workgroup
+    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k);
+    else if (single) return;
     else if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, NP / 16 + 1);
     // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
     //  been scheduled: every strip must run into its bounded wait and the host must recover the frame)
@@ -2018,7 +2085,8 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nu
     return 0;
 }
 
-// RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 4 fault injection (the chain
+// RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
+// shared route too, bit 4 fault injection (the chain
 // workgroup does not run); set_sweep_exp_mask overrides the environment (tests)
 static int g_sweep_exp_override = -1;
 void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }
