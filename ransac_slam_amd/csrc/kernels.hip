@@ -44,6 +44,11 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
     if (i >= L) return;                       // whole 16-lane group leaves together
     const bool is_id = (type[i] == 0);
     const int o = off[i];
+    const int w = is_id ? 13 : 10;
+    // lane `sub` owns column jj = sub of (H P): its 13 entries of P are requested first and arrive under the camera model
+    double pc[13];
+#pragma unroll
+    for (int kk = 0; kk < 13; ++kk) pc[kk] = (sub < w && kk < w) ? P[col_index(o, kk) + (long)col_index(o, sub) * NP] : 0.0;
     double u, v;
     const bool visible = predict_feature(cam, x, o, is_id, u, v);
     const bool had = has_h_in && (has_h_in[i] != 0);
@@ -62,17 +67,13 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
 #pragma unroll
         for (int k = 0; k < 26; ++k) H13[26 * i + k] = Hc[k];
     }
-    const int w = is_id ? 13 : 10;
-    // lane `sub` owns column jj = sub of (H P)
     double t0 = 0, t1 = 0, hj0 = 0, hj1 = 0;
     if (sub < w) {
-        const long cj = col_index(o, sub);
 #pragma unroll
         for (int kk = 0; kk < 13; ++kk) {
             if (kk < w) {
-                const double p = P[col_index(o, kk) + cj * NP];
-                t0 += Hc[kk] * p;
-                t1 += Hc[13 + kk] * p;
+                t0 += Hc[kk] * pc[kk];
+                t1 += Hc[13 + kk] * pc[kk];
             }
             if (kk == sub) { hj0 = Hc[kk]; hj1 = Hc[13 + kk]; }
         }
@@ -146,10 +147,12 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
     if (row >= NP) return;
     const int w = (type[f] == 0) ? 13 : 10;
     double a0 = 0, a1 = 0;
-    for (int k = 0; k < w; ++k) {
-        const double p = P[row + (long)col_index(o, k) * NP];
-        a0 += p * Hf[k];
-        a1 += p * Hf[13 + k];
+    double pv[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? P[row + (long)col_index(o, k) * NP] : 0.0;     // all thirteen in flight at once
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        if (k < w) { a0 += pv[k] * Hf[k]; a1 += pv[k] * Hf[13 + k]; }
     }
     out[row + (long)(2 * c) * ldo] = a0;
     out[row + (long)(2 * c + 1) * ldo] = a1;
@@ -309,7 +312,37 @@ void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos
 constexpr int SEL_MAX_THREADS = 1024;
 constexpr int SEL_MAX_RECORDS = 4096;
 
-// all threads of the block; blockDim.x <= SEL_MAX_THREADS; result in sel[0..2]
+// block-wide scans on wave shuffles: two barriers each instead of two per doubling step
+__device__ __forceinline__ int block_excl_max(int v, int* s_w)           // max over the threads before this one (values >= 0)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc = max(inc, o); }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before = max(before, s_w[w]);
+    const int prev = __shfl_up(inc, 1, 64);
+    __syncthreads();
+    return lane > 0 ? max(before, prev) : before;
+}
+__device__ __forceinline__ int block_incl_sum(int v, int* s_w, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < nw; ++w) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+    __syncthreads();
+    *total = all;
+    return before + inc;
+}
+
+// all threads of the block; blockDim.x <= SEL_MAX_THREADS and a multiple of 64; result in sel[0..2]
 __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table,
                                  int adaptive, int n_hyp_init, int32_t* __restrict__ sel,
                                  int* s_max, int* s_cnt, int* s_rec)
@@ -319,41 +352,28 @@ __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const i
     const int lo = min(H, t * chunk), hi = min(H, lo + chunk);
     int mx = 0;
     for (int i = lo; i < hi; ++i) mx = max(mx, sup[i]);
-    s_max[t] = mx;
-    __syncthreads();
-    for (int d = 1; d < nt; d <<= 1) {                 // inclusive prefix max
-        const int other = (t >= d) ? s_max[t - d] : 0;
-        __syncthreads();
-        s_max[t] = max(s_max[t], other);
-        __syncthreads();
-    }
-    int run = (t > 0) ? s_max[t - 1] : 0;              // max of everything before the chunk (supports >= 0)
+    const int before = block_excl_max(mx, s_max);       // max of everything before the chunk (supports >= 0)
+    int run = before;
     int cnt = 0;
     for (int i = lo; i < hi; ++i) { const int v = sup[i]; if (v > run) { run = v; ++cnt; } }
-    s_cnt[t] = cnt;
-    __syncthreads();
-    for (int d = 1; d < nt; d <<= 1) {                 // inclusive prefix sum
-        const int other = (t >= d) ? s_cnt[t - d] : 0;
-        __syncthreads();
-        s_cnt[t] += other;
-        __syncthreads();
-    }
-    int wpos = s_cnt[t] - cnt;
-    run = (t > 0) ? s_max[t - 1] : 0;
+    int total = 0;
+    int wpos = block_incl_sum(cnt, s_max, &total) - cnt;
+    run = before;
     for (int i = lo; i < hi; ++i) {
         const int v = sup[i];
-        if (v > run) { run = v; if (wpos < SEL_MAX_RECORDS) s_rec[wpos] = i; ++wpos; }
+        if (v > run) { run = v; if (wpos < SEL_MAX_RECORDS) { s_rec[wpos] = i; if (wpos < SEL_MAX_THREADS) s_cnt[wpos] = v; } ++wpos; }
     }
+    if (t == 0) s_max[0] = total;
     __syncthreads();
     if (t == 0) {
-        const int nrec = min(s_cnt[nt - 1], SEL_MAX_RECORDS);
+        const int nrec = min(s_max[0], SEL_MAX_RECORDS);
         int n_hyp = adaptive ? n_hyp_init : H;
         int best = 0, besti = -1, evaluated = 0, last = 0;
         bool done = false;
         for (int k = 0; k < nrec && !done; ++k) {
             const int i = s_rec[k];
             if (i >= n_hyp || i >= H) break;           // loop ended before reaching this record
-            best = sup[i]; besti = i; last = i + 1;
+            best = k < SEL_MAX_THREADS ? s_cnt[k] : sup[i]; besti = i; last = i + 1;   // (the record's support sits beside its index)
             if (adaptive) {
                 n_hyp = nhyp_table[best];
                 if (n_hyp == 0 || i > n_hyp) { evaluated = i + 1; done = true; }   // the two breaks, :533,:536
