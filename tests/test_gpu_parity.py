@@ -299,6 +299,33 @@ def test_persistent_sweep_timeout_falls_back(hip, oracle_lib):
     g.close()
 
 
+@pytest.mark.parametrize("compat,L,H,seed", [(1, 90, 120, 11), (0, 24, 60, 12), (0, 90, 120, 13)])
+def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed):
+    """A system of one diagonal block (r <= 64) is factored by every strip workgroup itself, with no hand-over between
+    workgroups; the shared route (chain workgroup + flags, forced by RSLAM_SWEEP_EXP bit 2) runs the same arithmetic on the
+    same numbers: the posterior must be bit-identical.  (compat = 1: the LI update is always rank 2.)"""
+    import ctypes as C
+    fr = make_frame(L=L, H=H, seed=seed)
+    cfg = default_config(compat=compat, adaptive=0)
+    lib = hip.lib()
+    lib.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
+    out = []
+    for mask in (-1, 4):
+        lib.rslam_debug_set_sweep_exp(mask)
+        try:
+            g = hip.RslamHip(cfg)
+            _, vis, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+            ic = (fr.ic & vis).astype(np.uint8)
+            out.append(g.ransac_update(fr.z, ic, fr.draws))
+            g.close()
+        finally:
+            lib.rslam_debug_set_sweep_exp(-1)
+    a, b = out
+    assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
+    assert np.array_equal(a["x_new"], b["x_new"])
+    assert np.array_equal(a["P_new"], b["P_new"])
+
+
 def test_two_phase_graph_frame_equals_full(hip):
     """The multi-GPU frame (two replayed graphs around the exchange) on one GPU, slice = everything."""
     import torch
