@@ -1476,7 +1476,7 @@ template <int NJ>
 __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, int nblk, int strip, int r_total, int NP,
                                             const SysSrc& src, const double* Linv, double* Ypanel, SweepFlags* fl,
                                             int32_t* status, double* lds, unsigned long long* dbg,
-                                            bool single, const int32_t* sel, int slot_k)
+                                            bool single, const int32_t* sel, int slot_k, bool tiny_off)
 {
     constexpr int NH = (NJ + 1) / 2;                        // column blocks per group
     const int b = strip >> 2;                               // 64-row block of the strip
@@ -1567,6 +1567,43 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
         // entries), factors it in its own LDS with the eight-wave pipeline of the chain workgroup -- the pivot chain stops
         // after r pivots -- and solves its rows: no hand-over hop (~3 us each) in either direction and no chain workgroup.
         // Same arithmetic as the shared route (lower triangle of S authoritative, same factor code): bit-identical Y.
+        if (r_total <= 4 && !tiny_off) {
+            // ... and a system of at most four rows (the rank-2 LI update of the reference-faithful mode) needs no pipeline
+            // at all: the 4 x 4 lower triangle of S goes round wave 0 in shuffles, every lane factors it in registers
+            // (sqrt / division at full precision) and solves its own row; the other columns of Y are zero.
+            if (g != 0) return;
+            if (w == 0) {
+                const int e = l & 15, ea = e >> 2, ec = e & 3;
+                const int a = ea >= ec ? ea : ec, c = ea >= ec ? ec : ea;      // lower triangle authoritative
+                double v = (a == c) ? 1.0 : 0.0;
+                if (a < r_total) {
+                    const int fa = src.list[a >> 1];
+                    const int fo = src.off[fa], fw = (src.type[fa] == 0) ? 13 : 10;
+                    const double* hf = src.H13 + 26L * fa + 13 * (a & 1);
+                    const double* wc = sys_wcol(src, A, ldA, NP, RP, c);
+                    double sacc = 0;
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) if (k < fw) sacc += hf[k] * wc[col_index(fo, k)];
+                    v += sacc;
+                }
+                const double s00 = __shfl(v, 0), s10 = __shfl(v, 4), s11 = __shfl(v, 5), s20 = __shfl(v, 8), s21 = __shfl(v, 9),
+                             s22 = __shfl(v, 10), s30 = __shfl(v, 12), s31 = __shfl(v, 13), s32 = __shfl(v, 14), s33 = __shfl(v, 15);
+                const double l00 = sqrt(s00), l10 = s10 / l00, l20 = s20 / l00, l30 = s30 / l00;
+                const double d1 = s11 - l10 * l10, l11 = sqrt(d1), l21 = (s21 - l20 * l10) / l11, l31 = (s31 - l30 * l10) / l11;
+                const double d2 = s22 - l20 * l20 - l21 * l21, l22 = sqrt(d2), l32 = (s32 - l30 * l20 - l31 * l21) / l22;
+                const double d3 = s33 - l30 * l30 - l31 * l31 - l32 * l32, l33 = sqrt(d3);
+                if (l == 0 && !(s00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0 && l33 < 1.0e300)) atomicMin(status, -6);   // RSLAM_ERR_NOT_SPD
+                // row ln of the strip: its four entries sit in lanes ln, ln + 16, ln + 32, ln + 48 (register 0)
+                const double q0 = __shfl(acc[0][0], ln), q1 = __shfl(acc[0][0], ln + 16), q2 = __shfl(acc[0][0], ln + 32), q3 = __shfl(acc[0][0], ln + 48);
+                const double x0 = q0 / l00, x1 = (q1 - x0 * l10) / l11, x2 = (q2 - x0 * l20 - x1 * l21) / l22,
+                             x3 = (q3 - x0 * l30 - x1 * l31 - x2 * l32) / l33;
+                acc[0][0] = lq == 0 ? x0 : lq == 1 ? x1 : lq == 2 ? x2 : x3;
+            }
+            double* dst = Ypanel + 16L * strip + ln + (16L * w + lq) * ldA;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dst[(4L * reg) * ldA] = (w == 0 && reg == 0) ? acc[0][0] : 0.0;
+            return;
+        }
         CdShared& sh = *reinterpret_cast<CdShared*>(lds);
         CdPre pre;
 #pragma unroll
@@ -2041,7 +2078,7 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
     if (nblk <= 0) return;
     const int r_total = 2 * sel[slot_k];
     const bool single = (nblk == 1) && !(exp_mask & 4);       // one diagonal block: every strip factors it itself, no chain workgroup
-    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k);
+    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k, (exp_mask & 8) != 0);
     else if (single) return;
     else if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, NP / 16 + 1);
     // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
@@ -2106,7 +2143,7 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nu
 }
 
 // RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
-// shared route too, bit 4 fault injection (the chain
+// shared route too, bit 3 no register-only route for systems of <= 4 rows, bit 4 fault injection (the chain
 // workgroup does not run); set_sweep_exp_mask overrides the environment (tests)
 static int g_sweep_exp_override = -1;
 void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }

@@ -303,27 +303,31 @@ def test_persistent_sweep_timeout_falls_back(hip, oracle_lib):
 def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed):
     """A system of one diagonal block (r <= 64) is factored by every strip workgroup itself, with no hand-over between
     workgroups; the shared route (chain workgroup + flags, forced by RSLAM_SWEEP_EXP bit 2) runs the same arithmetic on the
-    same numbers: the posterior must be bit-identical.  (compat = 1: the LI update is always rank 2.)"""
+    same numbers: the posterior must be bit-identical.  Systems of <= 4 rows (compat = 1: the LI update is always rank 2)
+    take a register-only route with full-precision sqrt / division (bit 3 switches it off): equal to rounding."""
     import ctypes as C
     fr = make_frame(L=L, H=H, seed=seed)
     cfg = default_config(compat=compat, adaptive=0)
     lib = hip.lib()
     lib.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
-    out = []
-    for mask in (-1, 4):
+    out = {}
+    for mask in (0, 8, 4):
         lib.rslam_debug_set_sweep_exp(mask)
         try:
             g = hip.RslamHip(cfg)
             _, vis, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
             ic = (fr.ic & vis).astype(np.uint8)
-            out.append(g.ransac_update(fr.z, ic, fr.draws))
+            out[mask] = g.ransac_update(fr.z, ic, fr.draws)
             g.close()
         finally:
             lib.rslam_debug_set_sweep_exp(-1)
-    a, b = out
+    a, b, c = out[8], out[4], out[0]
     assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
     assert np.array_equal(a["x_new"], b["x_new"])
     assert np.array_equal(a["P_new"], b["P_new"])
+    assert np.array_equal(c["li"], b["li"]) and np.array_equal(c["hi"], b["hi"])
+    assert np.allclose(c["x_new"], b["x_new"], rtol=1e-12, atol=1e-13)
+    assert np.allclose(c["P_new"], b["P_new"], rtol=1e-11, atol=1e-13)
 
 
 def test_two_phase_graph_frame_equals_full(hip):
