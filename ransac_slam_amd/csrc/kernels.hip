@@ -2299,18 +2299,19 @@ __device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int3
 __global__ void __launch_bounds__(256)
 rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
                    const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                   const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k, XuArgs xu)
+                   const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k, XuArgs xu,
+                   int rider0 /* first workgroup of the x update: 0 (then the tiles follow) or the number of tiles */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // The first xu.groups workgroups are K9 riding along: x_k_k = x + Y u needs the same finished sweep as this
     // kernel and nothing of its output, so it does not deserve a launch of its own.  Group 0 also produces Jnorm,
     // which the bj == 0 tiles below wait for (they are dispatched after it and need it ~50 us later).
-    if ((int)blockIdx.x < xu.groups) {
-        xupdate_rows(blockIdx.x, xu.d, sel, slot_nblk, slot_k, xu.A, xu.x_in, xu.x_out, xu.T, xu.compat, xu.flag, xu.token,
+    if ((int)blockIdx.x >= rider0 && (int)blockIdx.x < rider0 + xu.groups) {
+        xupdate_rows((int)blockIdx.x - rider0, xu.d, sel, slot_nblk, slot_k, xu.A, xu.x_in, xu.x_out, xu.T, xu.compat, xu.flag, xu.token,
                      reinterpret_cast<double (*)[17]>(lds));
         return;
     }
-    const int tile_index = blockIdx.x - xu.groups;
+    const int tile_index = rider0 == 0 ? (int)blockIdx.x - xu.groups : (int)blockIdx.x;
     int bi, bj;
     if (tile_order) {
         // XCD-aware order (make_rank_update_order): the tiles one XCD's L2 sees form 8 x 8 regions of
@@ -2469,8 +2470,19 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
     if (tiles <= 0) return;
     XuArgs none{}; none.groups = 0;
     const XuArgs& x = xu ? *xu : none;
+    // Where the x update rides: in front of the tiles (dispatched first: its Jnorm is out long before the tiles of the first
+    // block column ask for it) -- unless every tile finds a slot at once (two workgroups per CU) and slots are left over:
+    // then the riders go last, group 0 still starts at once, and no tile waits for a rider to vacate its slot (the late
+    // tiles ended the launch ~2 us late at C3).
+    static int slots = -1;
+    if (slots < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 0;
+    }
+    static const bool riders_first = getenv("RSLAM_K10_RIDERS_FIRST") != nullptr;      // measurement
+    const int rider0 = (x.groups > 0 && tiles < slots && !riders_first) ? tiles : 0;
     rank_update_kernel<<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
-                                                                                             fixed_k, Pout, ldo, tile_order, Tq, slot_k, x);
+                                                                                             fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, rider0);
 }
 
 // ---------------------------------------------------------------------------
