@@ -2300,7 +2300,8 @@ __global__ void __launch_bounds__(256)
 rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
                    const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
                    const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k, XuArgs xu,
-                   int rider0 /* first workgroup of the x update: 0 (then the tiles follow) or the number of tiles */)
+                   int rider0 /* first workgroup of the x update: 0 (then the tiles follow) or the number of tiles */,
+                   unsigned long long* dbg /* nullable: [workgroup][4] = start, K loop entered, K loop done, end (100 MHz) + hw id */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // The first xu.groups workgroups are K9 riding along: x_k_k = x + Y u needs the same finished sweep as this
@@ -2312,6 +2313,12 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         return;
     }
     const int tile_index = rider0 == 0 ? (int)blockIdx.x - xu.groups : (int)blockIdx.x;
+    if (dbg && threadIdx.x == 0) {
+        dbg[8L * blockIdx.x + 0] = wall_clock64();
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[8L * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
     int bi, bj;
     if (tile_order) {
         // XCD-aware order (make_rank_update_order): the tiles one XCD's L2 sees form 8 x 8 regions of
@@ -2357,7 +2364,9 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     }
     TgAcc acc;
     tg_zero(acc);
+    if (dbg && threadIdx.x == 0) dbg[8L * blockIdx.x + 1] = wall_clock64();
     tile_gemm_nt_dma(Y + (long)bi * 64, ldy, Y + (long)bj * 64, ldy, K, lds, acc);
+    if (dbg && threadIdx.x == 0) dbg[8L * blockIdx.x + 2] = wall_clock64();
     double* Cs = lds;
     double* Ts = lds + TS_DOUBLES;
     tg_acc_to_lds(acc, Cs, 1.0);
@@ -2441,6 +2450,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
             Cji[row + (long)c * ldo] = Cs[row * TS_LD + c];
         }
     }
+    if (dbg && threadIdx.x == 0) { dbg[8L * blockIdx.x + 3] = wall_clock64(); dbg[8L * blockIdx.x + 5] = ((unsigned long long)bi << 16) | bj; }
 }
 
 // Tile order for rank_update_kernel.  Workgroups are dealt round-robin over the 8 XCDs (block b
@@ -2459,6 +2469,21 @@ void make_rank_update_order(int nT, std::vector<int32_t>& order)
         const int x = b % 8, idx = b / 8;
         order[b] = seq[x * q + (x < r ? x : r) + idx];
     }
+}
+
+// diagnostic time stamps of the rank update (the last launch wins); off unless a buffer is installed
+static unsigned long long* g_k10_dbg = nullptr;
+constexpr int K10_DBG_WGS = 8192;
+int debug_k10_stamps(unsigned long long* out /* K10_DBG_WGS * 8, nullable */, int enable)
+{
+    const size_t bytes = sizeof(unsigned long long) * K10_DBG_WGS * 8;
+    if (enable && !g_k10_dbg) {
+        if (hipMalloc((void**)&g_k10_dbg, bytes) != hipSuccess) { g_k10_dbg = nullptr; return -1; }
+        (void)hipMemset(g_k10_dbg, 0, bytes);
+    }
+    if (out && g_k10_dbg) { if (hipMemcpy(out, g_k10_dbg, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1; (void)hipMemset(g_k10_dbg, 0, bytes); }
+    if (!enable && g_k10_dbg) { (void)hipFree(g_k10_dbg); g_k10_dbg = nullptr; }
+    return 0;
 }
 
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
@@ -2482,7 +2507,8 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
     static const bool riders_first = getenv("RSLAM_K10_RIDERS_FIRST") != nullptr;      // measurement
     const int rider0 = (x.groups > 0 && tiles < slots && !riders_first) ? tiles : 0;
     rank_update_kernel<<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
-                                                                                             fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, rider0);
+                                                                                             fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, rider0,
+                                                                                             (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);
 }
 
 // ---------------------------------------------------------------------------

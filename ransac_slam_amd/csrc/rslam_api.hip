@@ -1396,6 +1396,16 @@ extern "C" int rslam_debug_sweep_stamps(rslam_ctx* c, unsigned long long* out, i
     return rslam::debug_sweep_stamps(out, enable) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
 }
 
+namespace rslam { int debug_k10_stamps(unsigned long long* out, int enable); }
+extern "C" int rslam_debug_k10_stamps(rslam_ctx* c, unsigned long long* out, int enable)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    invalidate_graph(c);                      // captured launches hold the old debug pointer
+    return rslam::debug_k10_stamps(out, enable) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
+}
+
 #if defined(CD_STAMPS)
 namespace rslam { int debug_read_cd_stamps(unsigned long long* out, int reset); }
 extern "C" int rslam_debug_cd_stamps(rslam_ctx* c, unsigned long long* out, int reset)
