@@ -2257,7 +2257,8 @@ __device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int3
     const double* Y = A + d.RP;
     const double* u = A + d.RP + d.NP;
     double acc = 0;
-    for (int k = sl; k < K; k += 16) acc += Y[row + (long)k * d.ldA] * u[(long)k * d.ldA];
+#pragma unroll 8
+    for (int k = sl; k < K; k += 16) acc += Y[row + (long)k * d.ldA] * u[(long)k * d.ldA];     // (eight load pairs in flight)
     part[sl][r] = acc;
     __syncthreads();
     if (sl == 0) {
