@@ -385,6 +385,7 @@ __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const i
         sel[SEL_BEST_HYP] = besti;
         sel[SEL_BEST_SUPPORT] = best;
         sel[SEL_HYPS_EVALUATED] = evaluated;
+        s_max[1] = besti;                               // for the caller, without a trip through memory
     }
     __syncthreads();
 }
@@ -427,7 +428,7 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
     if (threadIdx.x == 0) s_running = 0;
     for (int i = threadIdx.x; i < L; i += blockDim.x) li[i] = 0;
     __syncthreads();
-    const int best = ((volatile int32_t*)sel)[SEL_BEST_HYP];
+    const int best = s_max[1];                          // (= sel[SEL_BEST_HYP], left there by select_consensus)
     if (best >= 0) {
         HypCtx hc;
         hyp_setup(x, W, NP, wv, pos[best], hc);
