@@ -299,8 +299,11 @@ def test_persistent_sweep_timeout_falls_back(hip, oracle_lib):
     g.close()
 
 
-@pytest.mark.parametrize("compat,L,H,seed", [(1, 90, 120, 11), (0, 24, 60, 12), (0, 90, 120, 13)])
-def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed):
+# (LI inliers of these frames: 1 -> r = 2 and 2 -> r = 4: the register-only route; 10 and 29 -> r = 20, 58: the in-LDS pipeline of
+#  every strip; the last one has several diagonal blocks: the shared route in any case)
+@pytest.mark.parametrize("compat,L,H,seed,n_li", [(1, 90, 120, 21, 1), (0, 6, 30, 43, 2), (0, 24, 60, 12, 10), (0, 40, 80, 13, 29),
+                                                  (0, 90, 120, 13, None)])
+def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed, n_li):
     """A system of one diagonal block (r <= 64) is factored by every strip workgroup itself, with no hand-over between
     workgroups; the shared route (chain workgroup + flags, forced by RSLAM_SWEEP_EXP bit 2) runs the same arithmetic on the
     same numbers: the posterior must be bit-identical.  Systems of <= 4 rows (compat = 1: the LI update is always rank 2)
@@ -322,6 +325,8 @@ def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed):
         finally:
             lib.rslam_debug_set_sweep_exp(-1)
     a, b, c = out[8], out[4], out[0]
+    if n_li is not None:
+        assert int(b["li"].sum()) == n_li          # the frame still exercises the route it was picked for
     assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
     assert np.array_equal(a["x_new"], b["x_new"])
     assert np.array_equal(a["P_new"], b["P_new"])
