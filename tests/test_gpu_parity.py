@@ -335,6 +335,18 @@ def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed, n_li):
     assert np.allclose(c["P_new"], b["P_new"], rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("compat,L,H,seed,n_li", [(1, 90, 120, 21, 1), (1, 90, 120, 33, 1), (0, 6, 30, 43, 2), (0, 6, 30, 38, 2),
+                                                  (0, 24, 60, 12, 10), (0, 40, 80, 13, 29)])
+def test_small_li_systems_match_oracle(hip, oracle_lib, compat, L, H, seed, n_li):
+    """LI updates of one diagonal block against the oracle: r = 2 and 4 (factored in registers by every strip) and
+    r = 20, 58 (factored in every strip's LDS) -- frames picked for their LI inlier count."""
+    fr = make_frame(L=L, H=H, seed=seed)
+    o, g, r0, r1 = run_both(hip, oracle_lib, fr, default_config(compat=compat, adaptive=0))
+    assert int(r0["li"].sum()) == n_li
+    check_frame(o, g, r0, r1)
+    g.close()
+
+
 def test_two_phase_graph_frame_equals_full(hip):
     """The multi-GPU frame (two replayed graphs around the exchange) on one GPU, slice = everything."""
     import torch
