@@ -199,22 +199,12 @@ __device__ __forceinline__ bool predict_feature(const Cam& cam, const double* x,
 // Follows Tracking::calculate_Hi_inverse_depth (src/Tracking.cpp:113-163),
 // calculate_Hi_cartesian (:71-112), jacob_undistor_fm (src/ExtendKF.cpp:312-332)
 // and dRq_times_a_by_dq (:286-311).
-__device__ __forceinline__ void feature_jacobian(const Cam& cam, const double* x, int off, bool is_id,
-                                                 double hu_, double hv_, double H13[26])
+// The Jacobian in two steps, so that the part that does not depend on the predicted pixel can run beside the prediction
+// (predict_kernel gives them to two waves): jacobian_core = a2 * D (2 x 13; a2 = d pinhole / d hc, D = d hc / d state),
+// jacobian_finish = a1 * (that), a1 = jacob_undistor_fm(h)^-1 (fixed 2x2 closed form).  Same terms as the reference's
+// (a1 a2) D, associated the other way round.
+__device__ __forceinline__ void jacobian_core(const Cam& cam, const double* x, int off, bool is_id, double B13[26])
 {
-    // a1 = jacob_undistor_fm(h)^-1  (fixed 2x2 closed form)
-    const double du = hu_ - cam.Cx, dv = hv_ - cam.Cy;
-    const double xd = du * cam.dx, yd = dv * cam.dy;
-    const double rd2 = xd * xd + yd * yd;
-    const double g = 1 + cam.k1 * rd2 + cam.k2 * rd2 * rd2;
-    const double gk = cam.k1 + 2 * cam.k2 * rd2;
-    const double uu_ud = g + du * gk * (2 * du * cam.dx * cam.dx);
-    const double vu_vd = g + dv * gk * (2 * dv * cam.dy * cam.dy);
-    const double uu_vd = du * gk * (2 * dv * cam.dy * cam.dy);
-    const double vu_ud = dv * gk * (2 * du * cam.dx * cam.dx);
-    const double idet = 1.0 / (uu_ud * vu_vd - uu_vd * vu_ud);
-    const double a1_00 = vu_vd * idet, a1_01 = -uu_vd * idet, a1_10 = -vu_ud * idet, a1_11 = uu_ud * idet;
-
     double Rq[9], Rrw[9], arg[3], mi[3], hc[3];
     q2r(x + 3, Rq);
     inv3(Rq, Rrw);
@@ -224,10 +214,8 @@ __device__ __forceinline__ void feature_jacobian(const Cam& cam, const double* x
     const double fku = cam.f * (1 / cam.dx), fkv = cam.f * (1 / cam.dy);
     const double a2_00 = fku / hc[2], a2_02 = -hc[0] * fku / (hc[2] * hc[2]);
     const double a2_11 = fkv / hc[2], a2_12 = -hc[1] * fkv / (hc[2] * hc[2]);
-    // a12 = a1 * a2 (2x3), rows p, cols k
-    double a12[2][3];
-    a12[0][0] = a1_00 * a2_00;  a12[0][1] = a1_01 * a2_11;  a12[0][2] = a1_00 * a2_02 + a1_01 * a2_12;
-    a12[1][0] = a1_10 * a2_00;  a12[1][1] = a1_11 * a2_11;  a12[1][2] = a1_10 * a2_02 + a1_11 * a2_12;
+    // B = a2 * D first (2 x 13; D = d hc / d state); the 2 x 2 factor a1, the only part that needs h, multiplies it at the end
+    const double a12[2][3] = { { a2_00, 0.0, a2_02 }, { 0.0, a2_11, a2_12 } };
     const double rho = is_id ? x[off + 5] : 1.0;
 
     // columns 0..2: a12 * (-Rrw) [* rho]
@@ -236,7 +224,7 @@ __device__ __forceinline__ void feature_jacobian(const Cam& cam, const double* x
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             double s = a12[p][0] * (-Rrw[0 + 3 * c]) + a12[p][1] * (-Rrw[1 + 3 * c]) + a12[p][2] * (-Rrw[2 + 3 * c]);
-            H13[p * 13 + c] = is_id ? s * rho : s;
+            B13[p * 13 + c] = is_id ? s * rho : s;
         }
     // columns 3..6: a12 * dRq_times_a_by_dq(qconj, arg) * diag(1,-1,-1,-1)
     {
@@ -263,7 +251,7 @@ __device__ __forceinline__ void feature_jacobian(const Cam& cam, const double* x
             const double sgn = (c == 0) ? 1.0 : -1.0;
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                H13[p * 13 + 3 + c] = a12[p][0] * (b0[0][c] * sgn) + a12[p][1] * (b0[1][c] * sgn) + a12[p][2] * (b0[2][c] * sgn);
+                B13[p * 13 + 3 + c] = a12[p][0] * (b0[0][c] * sgn) + a12[p][1] * (b0[1][c] * sgn) + a12[p][2] * (b0[2][c] * sgn);
         }
     }
     // feature columns
@@ -287,16 +275,44 @@ __device__ __forceinline__ void feature_jacobian(const Cam& cam, const double* x
         for (int c = 0; c < 6; ++c)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                H13[p * 13 + 7 + c] = a12[p][0] * c0[0][c] + a12[p][1] * c0[1][c] + a12[p][2] * c0[2][c];
+                B13[p * 13 + 7 + c] = a12[p][0] * c0[0][c] + a12[p][1] * c0[1][c] + a12[p][2] * c0[2][c];
     } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                H13[p * 13 + 7 + c] = a12[p][0] * Rrw[0 + 3 * c] + a12[p][1] * Rrw[1 + 3 * c] + a12[p][2] * Rrw[2 + 3 * c];
-                H13[p * 13 + 10 + c] = 0.0;
+                B13[p * 13 + 7 + c] = a12[p][0] * Rrw[0 + 3 * c] + a12[p][1] * Rrw[1 + 3 * c] + a12[p][2] * Rrw[2 + 3 * c];
+                B13[p * 13 + 10 + c] = 0.0;
             }
     }
+}
+
+__device__ __forceinline__ void jacobian_finish(const Cam& cam, double hu_, double hv_, const double B13[26], double H13[26])
+{
+    const double du = hu_ - cam.Cx, dv = hv_ - cam.Cy;
+    const double xd = du * cam.dx, yd = dv * cam.dy;
+    const double rd2 = xd * xd + yd * yd;
+    const double g = 1 + cam.k1 * rd2 + cam.k2 * rd2 * rd2;
+    const double gk = cam.k1 + 2 * cam.k2 * rd2;
+    const double uu_ud = g + du * gk * (2 * du * cam.dx * cam.dx);
+    const double vu_vd = g + dv * gk * (2 * dv * cam.dy * cam.dy);
+    const double uu_vd = du * gk * (2 * dv * cam.dy * cam.dy);
+    const double vu_ud = dv * gk * (2 * du * cam.dx * cam.dx);
+    const double idet = 1.0 / (uu_ud * vu_vd - uu_vd * vu_ud);
+    const double a1_00 = vu_vd * idet, a1_01 = -uu_vd * idet, a1_10 = -vu_ud * idet, a1_11 = uu_ud * idet;
+#pragma unroll
+    for (int c = 0; c < 13; ++c) {
+        H13[c]      = a1_00 * B13[c] + a1_01 * B13[13 + c];
+        H13[13 + c] = a1_10 * B13[c] + a1_11 * B13[13 + c];
+    }
+}
+
+__device__ __forceinline__ void feature_jacobian(const Cam& cam, const double* x, int off, bool is_id,
+                                                 double hu_, double hv_, double H13[26])
+{
+    double B13[26];
+    jacobian_core(cam, x, off, is_id, B13);
+    jacobian_finish(cam, hu_, hv_, B13, H13);
 }
 
 // state index of compact column c (0..12) of a feature at state offset off

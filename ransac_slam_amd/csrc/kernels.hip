@@ -31,38 +31,59 @@ namespace rslam {
 // 16 lanes per feature: the scalar camera/Jacobian arithmetic is done redundantly by the
 // group (latency-bound either way), the 13 x 13 gather of P for S_i is split one column
 // per lane and reduced with shuffles.
-__global__ void __launch_bounds__(64)
+// Two waves per four features: the kernel is ONE instruction stream of ~1900 vector instructions per feature (it runs at
+// 75 waves on 1024 SIMDs: its duration is that stream).  Wave 1 runs the part of the Jacobian that does not need the
+// predicted pixel (jacobian_core, ~860 instructions) while wave 0 runs the prediction (~830) and hands it over through LDS.
+__global__ void __launch_bounds__(128)
 predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ P, int NP, int L,
                const uint8_t* __restrict__ type, const int32_t* __restrict__ off,
                const double* __restrict__ h_in, const uint8_t* __restrict__ has_h_in,   // nullable: no previous h
                double* __restrict__ h, uint8_t* __restrict__ has_h, uint8_t* vis, double* __restrict__ H13,
                double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */)
 {
+    __shared__ double sB[4][26];
     if (sel_reset && blockIdx.x == 0 && threadIdx.x < SEL_COUNT) sel_reset[threadIdx.x] = 0;   // new frame
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const int grp = (threadIdx.x & 63) >> 4;
+    const int i = blockIdx.x * 4 + grp;
     const int sub = threadIdx.x & 15;
-    if (i >= L) return;                       // whole 16-lane group leaves together
-    const bool is_id = (type[i] == 0);
-    const int o = off[i];
+    const bool second = threadIdx.x >= 64;
+    const bool live = i < L;
+    const bool is_id = live && (type[i] == 0);
+    const int o = live ? off[i] : 0;
+    if (second) {
+        if (live) {
+            double Bc[26];
+            jacobian_core(cam, x, o, is_id, Bc);
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 26; ++k) sB[grp][k] = Bc[k];
+            }
+        }
+        __syncthreads();
+        return;
+    }
     const int w = is_id ? 13 : 10;
     // lane `sub` owns column jj = sub of (H P): its 13 entries of P are requested first and arrive under the camera model
     double pc[13];
 #pragma unroll
-    for (int kk = 0; kk < 13; ++kk) pc[kk] = (sub < w && kk < w) ? P[col_index(o, kk) + (long)col_index(o, sub) * NP] : 0.0;
-    double u, v;
-    const bool visible = predict_feature(cam, x, o, is_id, u, v);
-    const bool had = has_h_in && (has_h_in[i] != 0);
+    for (int kk = 0; kk < 13; ++kk) pc[kk] = (live && sub < w && kk < w) ? P[col_index(o, kk) + (long)col_index(o, sub) * NP] : 0.0;
+    double u = 0, v = 0;
+    const bool visible = live && predict_feature(cam, x, o, is_id, u, v);
+    const bool had = live && has_h_in && (has_h_in[i] != 0);
     const bool have = visible || had;
     double hu_ = u, hv_ = v;
     if (!visible && had) { hu_ = h_in[2 * i]; hv_ = h_in[2 * i + 1]; }    // stale h (ExtendKF.cpp:77-78)
-    if (sub == 0) {
+    if (live && sub == 0) {
         if (have) { h[2 * i] = hu_; h[2 * i + 1] = hv_; }
         has_h[i] = have ? 1 : 0;
         if (vis) vis[i] = visible ? 1 : 0;
     }
+    __syncthreads();                         // the other wave's half of the Jacobian is in LDS
     if (!have) return;
-    double Hc[26];
-    feature_jacobian(cam, x, o, is_id, hu_, hv_, Hc);
+    double Bc[26], Hc[26];
+#pragma unroll
+    for (int k = 0; k < 26; ++k) Bc[k] = sB[grp][k];
+    jacobian_finish(cam, hu_, hv_, Bc, Hc);
     if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 26; ++k) H13[26 * i + k] = Hc[k];
@@ -97,7 +118,7 @@ void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double
         if (sel_reset) (void)hipMemsetAsync(sel_reset, 0, sizeof(int32_t) * SEL_COUNT, s);
         return;
     }
-    predict_kernel<<<dim3((L + 3) / 4), dim3(64), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
+    predict_kernel<<<dim3((L + 3) / 4), dim3(128), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
                                                         sel_reset);
 }
 
