@@ -52,6 +52,8 @@ def lib():
         L.orc_finish_update.argtypes = [C.c_void_p, _dp, _dp, _u8p, _u8p]
         L.orc_get_supports.argtypes = [C.c_void_p, _i32p, _i32p, _u64p, _i32p]
         L.orc_get_margins.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_enable_residuals.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_residuals.argtypes = [C.c_void_p, _dp, _i32p]
         L.orc_get_H.argtypes = [C.c_void_p, _dp]
         L.orc_get_li_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_q2r.argtypes = [_dp, _dp]
@@ -176,6 +178,17 @@ class Oracle:
         masks = np.zeros((max(n_eval, 1), max(words.value, 1)), np.uint64)
         lib().orc_get_supports(self._h, _p(sup, _i32p), _p(pos, _i32p), _p(masks, _u64p), C.byref(words))
         return sup[:n_eval], pos[:n_eval], masks[:n_eval, :words.value]
+
+    def enable_residuals(self, on=True):
+        lib().orc_enable_residuals(self._h, 1 if on else 0)
+
+    def residuals(self):
+        """(m, m) residuals in pixels: row = rank of the hypothesised matched feature, NaN = never scored"""
+        m = C.c_int32()
+        lib().orc_get_residuals(self._h, None, C.byref(m))
+        out = np.full((max(m.value, 1), max(m.value, 1)), np.nan)
+        lib().orc_get_residuals(self._h, _p(out), C.byref(m))
+        return out[:m.value, :m.value]
 
     def margins(self):
         a, b = C.c_double(), C.c_double()

@@ -48,6 +48,10 @@ struct orc_ctx {
     int32_t* positions;
     uint64_t* masks;
     double   score_margin, rescue_margin;
+    /* residual capture for the value-level check of the device's scoring arithmetic (orc_enable_residuals):
+     * res[p * res_m + j] = residual (pixels) of matched feature j under the hypothesis of matched feature p */
+    int      res_on, res_m;
+    double*  res;
     double  *x_li, *p_li;
     int      predicted;
 };
@@ -319,7 +323,7 @@ int orc_destroy(orc_ctx* c)
 {
     if (!c) return RSLAM_ERR_ARG;
     free_frame(c);
-    free(c->supports); free(c->positions); free(c->masks);
+    free(c->supports); free(c->positions); free(c->masks); free(c->res);
     free(c);
     return RSLAM_OK;
 }
@@ -614,6 +618,12 @@ static int ransac_hypotheses(orc_ctx* c, const double* draws, int n_draws, int m
     int iters_cap = n_draws;
     if (max_iters > 0 && max_iters < iters_cap) iters_cap = max_iters;
     ensure_eval_capacity(c, iters_cap, words);
+    if (c->res_on) {
+        free(c->res);
+        c->res_m = m;
+        c->res = (double*)malloc(sizeof(double) * ((size_t)m * m + 1));
+        for (size_t q = 0; q < (size_t)m * m; ++q) c->res[q] = NAN;
+    }
     c->n_eval = 0;
     c->score_margin = DBL_MAX;
     *best_hyp = -1; *best_support = 0; *hyps_evaluated = 0;
@@ -714,6 +724,7 @@ static int ransac_hypotheses(orc_ctx* c, const double* draws, int n_draws, int m
                     const double n0 = c->z[2 * id_list[j]] - h_dist[0];
                     const double n1 = c->z[2 * id_list[j] + 1] - h_dist[1];
                     const double residual = sqrt(pow(n0, 2) + pow(n1, 2));
+                    if (c->res_on) c->res[(size_t)random_match_position * m + rank_of[id_list[j]]] = residual;
                     const double mg = fabs(residual - threshold);
                     if (mg < c->score_margin) c->score_margin = mg;
                     if (residual < threshold) {
@@ -741,6 +752,7 @@ static int ransac_hypotheses(orc_ctx* c, const double* draws, int n_draws, int m
                     const double n0 = c->z[2 * zsrc] - h_dist[0];
                     const double n1 = c->z[2 * zsrc + 1] - h_dist[1];
                     const double residual = sqrt(pow(n0, 2) + pow(n1, 2));
+                    if (c->res_on) c->res[(size_t)random_match_position * m + rank_of[euc_list[j]]] = residual;
                     const double mg = fabs(residual - threshold);
                     if (mg < c->score_margin) c->score_margin = mg;
                     if (residual < threshold) {
@@ -1705,6 +1717,24 @@ int orc_get_supports(orc_ctx* c, int32_t* supports, int32_t* positions, uint64_t
     if (masks) memcpy(masks, c->masks, sizeof(uint64_t) * (size_t)c->n_eval * (size_t)c->words);
     if (words) *words = c->words;
     return c->n_eval;
+}
+
+/* Residual capture (test infrastructure for the scoring kernel's value-level check): when on, the next RANSAC stage
+ * records sqrt(n0^2 + n1^2) of Tracking.cpp:472-476,499-503 for every (hypothesised matched feature, matched feature)
+ * pair it scores; orc_get_residuals copies the m x m table (row = hypothesised feature's rank, NaN = never scored). */
+int orc_enable_residuals(orc_ctx* c, int on)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    c->res_on = on ? 1 : 0;
+    return RSLAM_OK;
+}
+
+int orc_get_residuals(orc_ctx* c, double* out, int32_t* m)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (m) *m = c->res ? c->res_m : 0;
+    if (out && c->res) memcpy(out, c->res, sizeof(double) * (size_t)c->res_m * c->res_m);
+    return RSLAM_OK;
 }
 
 int orc_get_margins(orc_ctx* c, double* score_margin, double* rescue_margin)

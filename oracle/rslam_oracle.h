@@ -65,6 +65,10 @@ int orc_get_supports(orc_ctx* c, int32_t* supports /* hyps_evaluated */,
 /* smallest |residual - sigma_z| over all scored pairs, smallest |d2 - chi2|
  * over all rescue candidates (the margin audit of DESIGN.md) */
 int orc_get_margins(orc_ctx* c, double* score_margin, double* rescue_margin);
+/* residual capture: pixels, m x m (row = rank of the hypothesised matched feature, column = rank of the scored one;
+ * NaN where a position was never hypothesised); switch on before orc_ransac_update / orc_ransac_only */
+int orc_enable_residuals(orc_ctx* c, int on);
+int orc_get_residuals(orc_ctx* c, double* out /* m*m, nullable */, int32_t* m);
 /* dense Jacobians of the last linearisation, L * (2 x n) col-major blocks */
 int orc_get_H(orc_ctx* c, double* H);
 /* intermediate filter state after the low-innovation update */

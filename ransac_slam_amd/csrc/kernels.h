@@ -49,6 +49,12 @@ void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* 
                   const int32_t* pos_list /* nullable = identity */, int n_entries,
                   double threshold, int32_t* sup_out, uint64_t* masks_out);
 
+// diagnostics for the value-level tests of the scoring arithmetic: squared residuals of every (position, feature) pair;
+// distort_fm_score next to the ten-step distort_fm on caller-supplied undistorted pixels
+void launch_score_residuals(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP, const double* wv,
+                            const ScoreTables& tab, const double* z, int m, double* out /* m * m */);
+void launch_distort_probe(hipStream_t s, const Cam& cam, int n, const double* uv, double* out_score, double* out_ref);
+
 void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos, int hb, int he,
                         int32_t* sup);
 
@@ -70,8 +76,19 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
                            const uint8_t* type, const double* z, const double* h, double* A,
                            const double* Wsrc, const int32_t* rank_of, int32_t* sweep_flags /* SWEEP_FLAG_INTS, zeroed here; nullable */);
-constexpr int SWEEP_FLAG_INTS = 112;   // hand-over flags of the persistent factor sweep (kernels.hip SweepFlags)
+constexpr int SWEEP_FLAG_INTS = 112 + 256;   // hand-over flags of the persistent factor sweep (kernels.hip SweepFlags)
 bool sweep_persistent_eligible(const SystemDims& d);
+// The covariance side of an update done INSIDE the persistent sweep launch (K9, K10, K11 without launches of their own):
+// the compute units the sweep leaves idle run tile workers that keep P - Y Y^T of their lower-triangle tile pairs in MFMA
+// accumulators and consume each 64-column block of Y as the P H^T strips publish it; the strips accumulate x + Y u.
+struct WorkerArgs {
+    const double* Pin; long ldp; double* Pout; long ldo;   // Pout == nullptr: not fused (the caller launches the rank update)
+    const int32_t* tile_order; int nT;                     // XCD-aware tile list (nullable) and tiles per side
+    const double* x_in; double* x_out; double* T;          // K9: x_k_k, Jnorm (4 x 4)
+    int compat; int token; int32_t* xu_flag;               // token published in *xu_flag when x_k_k and Jnorm are out
+    int li_done_slot;                                      // sel[] slot that tells the HI pass whether the LI pass wrote P (mirror tiles equal), -1: never
+};
+bool sweep_fused_eligible(const SystemDims& d);            // enough idle compute units for every tile pair of P
 void set_sweep_exp_mask(int mask);     // -1 = environment (RSLAM_SWEEP_EXP); diagnostics and fault injection
 int sweep_exp_mask();
 // What the persistent sweep builds its stacked system [S; P H^T; nu^T] from (it has no prepare_system pass): the
@@ -85,7 +102,8 @@ struct SysSrc {
 double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
                             int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
                             int32_t* status_sel, int32_t* flags /* 2 * SWEEP_FLAG_INTS zeroed ints, or nullptr: never the persistent sweep */,
-                            const SysSrc* src /* with flags: the sweep assembles the system itself (no launch_prepare_system) */);
+                            const SysSrc* src /* with flags: the sweep assembles the system itself (no launch_prepare_system) */,
+                            const WorkerArgs* wk = nullptr /* persistent sweep only: x and covariance update inside the launch */);
 // K9 riding in the rank-update launch: the first `groups` workgroups compute x_k_k = x + Y u (16 rows each),
 // group 0 the quaternion normalisation and Jnorm, published through *flag = token (sel[SEL_XU_FLAG])
 struct XuArgs {

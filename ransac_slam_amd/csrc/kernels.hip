@@ -219,8 +219,9 @@ __device__ __forceinline__ void hyp_setup(const double* __restrict__ x, const do
         for (int b = 0; b < 3; ++b) hc.rot[a + 3 * b] = Rq[b + 3 * a];
 }
 
-__device__ __forceinline__ bool score_pair(const Cam& cam, const double* __restrict__ x, const HypCtx& hc,
-                                           const ScoreTables& tab, const double* __restrict__ z, int j, double thr)
+// squared residual |z_j - h_j(x_i)|^2 of matched feature j under the hypothesis hc (Tracking.cpp:425-476,480-503)
+__device__ __forceinline__ double score_residual2(const Cam& cam, const double* __restrict__ x, const HypCtx& hc,
+                                                  const ScoreTables& tab, const double* __restrict__ z, int j)
 {
     const int o = tab.off[j];
 #define XI(idx) (x[(idx)] + (hc.c0[(idx)] * hc.w0 + hc.c1[(idx)] * hc.w1))
@@ -259,7 +260,49 @@ __device__ __forceinline__ bool score_pair(const Cam& cam, const double* __restr
     distort_fm_score(cam, ui, vi, ud, vd);
     const int zf = tab.zsrc[j];
     const double n0 = z[2 * zf] - ud, n1 = z[2 * zf + 1] - vd;
-    return (n0 * n0 + n1 * n1) < thr * thr;
+    return n0 * n0 + n1 * n1;
+}
+
+__device__ __forceinline__ bool score_pair(const Cam& cam, const double* __restrict__ x, const HypCtx& hc,
+                                           const ScoreTables& tab, const double* __restrict__ z, int j, double thr)
+{
+    return score_residual2(cam, x, hc, tab, z, j) < thr * thr;
+}
+
+// diagnostic (tests): the residuals the scoring kernel compares with the threshold, for every hypothesised position
+__global__ void __launch_bounds__(256)
+score_residual_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
+                      const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m, double* __restrict__ out)
+{
+    const int p = blockIdx.x;
+    HypCtx hc;
+    hyp_setup(x, W, NP, wv, p, hc);
+    for (int j = threadIdx.x; j < m; j += blockDim.x) out[(long)p * m + j] = score_residual2(cam, x, hc, tab, z, j);
+}
+
+void launch_score_residuals(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP, const double* wv,
+                            const ScoreTables& tab, const double* z, int m, double* out)
+{
+    if (m <= 0) return;
+    score_residual_kernel<<<dim3(m), dim3(256), 0, s>>>(cam, x, W, NP, wv, tab, z, m, out);
+}
+
+// diagnostic (tests): distort_fm_score (six steps, raw reciprocal slopes) beside distort_fm (the reference's ten divisions)
+__global__ void distort_probe_kernel(Cam cam, int n, const double* __restrict__ uv, double* __restrict__ out_score, double* __restrict__ out_ref)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b;
+    distort_fm_score(cam, uv[2 * i], uv[2 * i + 1], a, b);
+    out_score[2 * i] = a; out_score[2 * i + 1] = b;
+    distort_fm(cam, uv[2 * i], uv[2 * i + 1], a, b);
+    out_ref[2 * i] = a; out_ref[2 * i + 1] = b;
+}
+
+void launch_distort_probe(hipStream_t s, const Cam& cam, int n, const double* uv, double* out_score, double* out_ref)
+{
+    if (n <= 0) return;
+    distort_probe_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(cam, n, uv, out_score, out_ref);
 }
 
 __global__ void __launch_bounds__(1024)
@@ -1377,7 +1420,7 @@ trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
 // bounded (status -3) so that a scheduling surprise ends in an error code, never in a hung queue.
 // ---------------------------------------------------------------------------
 // optional time stamps (100 MHz wall clock) of the persistent sweep: dbg[who][block/step][slot], see scripts/sweep_stamps.py
-constexpr int SWD_WHO = 5, SWD_K = 16, SWD_SLOT = 8;
+constexpr int SWD_WHO = 6, SWD_K = 16, SWD_SLOT = 8;      // who 5: tile worker 0
 __device__ __forceinline__ void sw_stamp(unsigned long long* dbg, int who, int k, int slot, int tid = 0)
 {
     if (dbg && (int)threadIdx.x == tid && k < SWD_K) dbg[(who * SWD_K + k) * SWD_SLOT + slot] = wall_clock64();
@@ -1392,6 +1435,8 @@ struct SweepFlags {
     int32_t panel_cnt[SW_MAX_BLOCKS];   // [k]: S strips that have published their rows of panel k (row blocks k+2 ..)
     int32_t row_ready[SW_MAX_BLOCKS];   // [b]: strips of S row block b that have handed tiles (b,b-1), (b,b) over
     int32_t row_cnt[SW_MAX_BLOCKS];     // [b]: panel rows published by the strips of S row block b, all steps (4 per step)
+    int32_t y_flag[256];                // [strip]: column blocks of Y (u^T) this P H^T (nu) strip has published -- one word per
+                                        // producer, no atomics: the tile workers poll the strips of their own row blocks
 };
 static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag block size");
 constexpr int SW_SPIN_LIMIT = 1 << 18;       // ~0.2 s; the longest legitimate wait is one diagonal block (~15 us)
@@ -1407,7 +1452,7 @@ __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)
 // hand-over costs one bound per workgroup, not one per wait.
 // Timeouts are reported as status -(30 + code) (the host maps everything <= -30 to RSLAM_ERR_HIP and keeps the raw value
 // for diagnosis): 1 L^-1 flag, 2 chain's panel row, 3 sibling strips, 4 all S strips, 5 hand-over (chain), 6 LDS pipeline
-// of the chain workgroup.
+// of the chain workgroup, 7 Y blocks (tile workers), 8 u^T / Jnorm (x update).
 __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* status, int* abort, int code = 0)
 {
     if (threadIdx.x == 0) {
@@ -1457,7 +1502,8 @@ __device__ __forceinline__ void sw_post_add(int32_t* flag)
 constexpr int CDP_AOP_DOUBLES = 64 * CD_OPLD;          // A(k,k-1): [m][CD_OPLD]
 constexpr int CDP_TPRE_DOUBLES = 40 * 64;              // tile (k,k): lower 16 x 16 tiles in accumulator layout [(idx, reg)][lane]
 constexpr size_t CDP_OFF_AOP = (sizeof(CdShared) + 15) / 16 * 2;     // in doubles
-constexpr size_t SWP_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
+constexpr size_t SWP_CHAIN_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
+constexpr size_t SWP_LDS_BYTES = SWP_CHAIN_LDS_BYTES > sizeof(double) * 2 * TD_LDS_DOUBLES ? SWP_CHAIN_LDS_BYTES : sizeof(double) * 2 * TD_LDS_DOUBLES;   // tile workers: two engines
 
 
 // compile-time loop: the accumulator array of a strip must never be indexed dynamically (it would move to scratch)
@@ -1494,11 +1540,74 @@ __device__ __forceinline__ double sys_S(const SysSrc& s, const double* A, long l
     return v;
 }
 
+// ---- K9 inside the sweep (fused launches, WorkerArgs): x_k_k = x + Y u --------------------------------------------------
+// The P H^T strips hold the rows of Y, the nu strip produces u^T block by block.  Thread (row = t & 15, pair = t >> 4)
+// of a P H^T strip accumulates Y(row, 2 pair .. 2 pair + 1) u over the column blocks, ONE STEP BEHIND the sweep (the X of
+// step k is still in the strip's LDS when step k + 1 begins, and by then the nu strip has long published u^T of block k:
+// no wait is ever exposed); after the last block the 32 partial sums of a row are added in a fixed order.  The strip of
+// state rows 0..15 also normalises the quaternion, writes Jnorm (ExtendKF.cpp:613-627; Q6) and publishes the token the
+// tile workers of the first block column wait for -- long before they reach their epilogue.
+struct XAcc {
+    double part;                // this thread's partial sum
+    int row, pair;
+};
+
+__device__ __forceinline__ void xacc_add(XAcc& xa, const double* Xs /* [64][16] */, const double* uT /* row RP + NP of Ypanel */,
+                                         long ldA, int kblk)
+{
+    const double x0 = Xs[(2 * xa.pair) * 16 + xa.row], x1 = Xs[(2 * xa.pair + 1) * 16 + xa.row];
+    const double u0 = ld_coh(uT + (64L * kblk + 2 * xa.pair) * ldA), u1 = ld_coh(uT + (64L * kblk + 2 * xa.pair + 1) * ldA);
+    xa.part = fma(x1, u1, fma(x0, u0, xa.part));
+}
+
+// quaternion normalisation and Jnorm from the updated pose (one thread); x[3..6] are overwritten with the unit quaternion
+__device__ __forceinline__ void quat_jnorm(double* xq /* x_k_k + 3, four entries, generic pointer */, int compat, double* T)
+{
+    const double qr = xq[0], qx = xq[1], qy = xq[2], qz = xq[3];
+    const double q2 = qr * qr + qx * qx + qy * qy + qz * qz;
+    const double nrm = sqrt(q2);
+    xq[0] = qr / nrm; xq[1] = qx / nrm; xq[2] = qy / nrm; xq[3] = qz / nrm;
+    const double scale = compat ? (1.0 / q2) : (1.0 / (q2 * nrm));
+    const double rows[16] = {
+        qx*qx+qy*qy+qz*qz, -qr*qx,           -qr*qy,           -qr*qz,
+        -qx*qr,            qr*qr+qy*qy+qz*qz, -qx*qy,          -qx*qz,
+        -qy*qr,            -qy*qx,           qr*qr+qx*qx+qz*qz, -qy*qz,
+        -qz*qr,            -qz*qx,           -qz*qy,           qr*qr+qx*qx+qy*qy };
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) st_coh(T + i + 4 * j, scale * rows[4 * i + j]);
+}
+
+// all threads of a P H^T strip: reduce the partial sums, write the strip's 16 rows of x_k_k; the strip of rows 0..15 also
+// publishes Jnorm + token.  scratch: 32 * 16 + 16 doubles of LDS nobody else is using.
+__device__ __forceinline__ void xacc_finish(const XAcc& xa, int first_row, const WorkerArgs& wk, double* scratch)
+{
+    const int t = threadIdx.x;
+    scratch[xa.pair * 16 + xa.row] = xa.part;
+    __syncthreads();
+    double* xs = scratch + 32 * 16;
+    if (t < 16) {
+        double ssum = 0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) ssum += scratch[q * 16 + t];
+        const double v = wk.x_in[first_row + t] + ssum;
+        xs[t] = v;
+        if (first_row != 0 || t < 3 || t > 6) wk.x_out[first_row + t] = v;
+    }
+    if (first_row != 0) return;
+    __syncthreads();
+    if (t == 0) {
+        double q[4] = { xs[3], xs[4], xs[5], xs[6] };
+        quat_jnorm(q, wk.compat, wk.T);
+        for (int i = 0; i < 4; ++i) wk.x_out[3 + i] = q[i];
+        wait_stores();
+        __hip_atomic_store(wk.xu_flag, wk.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int NJ>
 __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, int nblk, int strip, int r_total, int NP,
                                             const SysSrc& src, const double* Linv, double* Ypanel, SweepFlags* fl,
                                             int32_t* status, double* lds, unsigned long long* dbg,
-                                            bool single, const int32_t* sel, int slot_k, bool tiny_off)
+                                            bool single, const int32_t* sel, int slot_k, bool tiny_off, const WorkerArgs& wk, int exp_mask)
 {
     constexpr int NH = (NJ + 1) / 2;                        // column blocks per group
     const int b = strip >> 2;                               // 64-row block of the strip
@@ -1507,9 +1616,17 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     if (who < 0) dbg = nullptr;
     const bool is_s = b < rp_blocks;
     // padding rows of S; row blocks 0 and 1 are the chain's first two diagonal blocks, assembled by the lower strips together
+    // (the caller turns those workgroups into tile workers when the launch is fused)
     if (is_s && (b >= nblk || b <= 1)) return;
     if (b == (int)(ldA / 64) - 1 && (strip & 3) != 0) return;   // below nu^T there is only zero padding
     const int RP = 64 * rp_blocks;
+    const bool is_nu = (b == (int)(ldA / 64) - 1);
+    const bool fused = wk.Pout != nullptr;                  // x and covariance update inside this launch
+    const bool xrows = fused && !is_s && !is_nu;            // this strip holds 16 rows of Y: it accumulates their x + Y u
+    const bool publish = fused && !is_s && !(exp_mask & 32);   // (exp_mask & 32: fault injection -- Y blocks are never announced)
+    const int nu_strip = (int)(ldA / 16) - 4;
+    const int first_row = 16 * (strip - 4 * rp_blocks);     // state row of this strip's first row (P H^T strips)
+    const double* uT = Ypanel + RP + NP;                    // u^T = nu^T L^-T: row RP + NP of the second buffer
     const int ncols = is_s ? b + 1 : nblk;                  // column blocks held
     // steps k = 0 .. nsteps - 1, each followed by updates except the last of a P H^T strip.  S row block b stops after
     // step b-2: its step b-1 -- the panel block L(b,b-1) and the update of tile (b,b) -- is the chain's own prologue of
@@ -1521,6 +1638,8 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     double* Sk = lds;                  // [64][16]: the strip's column block k before the solve (B operand of the X product)
     double* Xs = lds + 64 * 16;        // [64][16]: X, the solved column block (B operand of the updates)
     int* abort = reinterpret_cast<int*>(lds + 2 * 64 * 16);
+    double* xscratch = lds + 2 * 64 * 16 + 2;              // 32 * 16 + 16 doubles for xacc_finish
+    XAcc xa; xa.part = 0.0; xa.row = t & 15; xa.pair = t >> 4;
     bool alive = true;
     if (t == 0) *abort = 0;            // (the first wait has a barrier before anybody reads it)
     if (!is_s && !single) {
@@ -1564,7 +1683,6 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
 #pragma unroll
             for (int k = 0; k < 13; ++k) Hf[k] = 0.0;
         }
-        const bool is_nu = (b == (int)(ldA / 64) - 1);
         static_for<0, NH>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
             acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1593,37 +1711,70 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
             // ... and a system of at most four rows (the rank-2 LI update of the reference-faithful mode) needs no pipeline
             // at all: the 4 x 4 lower triangle of S goes round wave 0 in shuffles, every lane factors it in registers
             // (sqrt / division at full precision) and solves its own row; the other columns of Y are zero.
-            if (g != 0) return;
-            if (w == 0) {
-                const int e = l & 15, ea = e >> 2, ec = e & 3;
-                const int a = ea >= ec ? ea : ec, c = ea >= ec ? ec : ea;      // lower triangle authoritative
-                double v = (a == c) ? 1.0 : 0.0;
-                if (a < r_total) {
-                    const int fa = src.list[a >> 1];
-                    const int fo = src.off[fa], fw = (src.type[fa] == 0) ? 13 : 10;
-                    const double* hf = src.H13 + 26L * fa + 13 * (a & 1);
-                    const double* wc = sys_wcol(src, A, ldA, NP, RP, c);
-                    double sacc = 0;
+            if (g == 0) {
+                if (w == 0) {
+                    const int e = l & 15, ea = e >> 2, ec = e & 3;
+                    const int a = ea >= ec ? ea : ec, c = ea >= ec ? ec : ea;      // lower triangle authoritative
+                    double v = (a == c) ? 1.0 : 0.0;
+                    if (a < r_total) {
+                        const int fa = src.list[a >> 1];
+                        const int fo = src.off[fa], fw = (src.type[fa] == 0) ? 13 : 10;
+                        const double* hf = src.H13 + 26L * fa + 13 * (a & 1);
+                        const double* wc = sys_wcol(src, A, ldA, NP, RP, c);
+                        double sacc = 0;
 #pragma unroll
-                    for (int k = 0; k < 13; ++k) if (k < fw) sacc += hf[k] * wc[col_index(fo, k)];
-                    v += sacc;
+                        for (int k = 0; k < 13; ++k) if (k < fw) sacc += hf[k] * wc[col_index(fo, k)];
+                        v += sacc;
+                    }
+                    const double s00 = __shfl(v, 0), s10 = __shfl(v, 4), s11 = __shfl(v, 5), s20 = __shfl(v, 8), s21 = __shfl(v, 9),
+                                 s22 = __shfl(v, 10), s30 = __shfl(v, 12), s31 = __shfl(v, 13), s32 = __shfl(v, 14), s33 = __shfl(v, 15);
+                    const double l00 = sqrt(s00), l10 = s10 / l00, l20 = s20 / l00, l30 = s30 / l00;
+                    const double d1 = s11 - l10 * l10, l11 = sqrt(d1), l21 = (s21 - l20 * l10) / l11, l31 = (s31 - l30 * l10) / l11;
+                    const double d2 = s22 - l20 * l20 - l21 * l21, l22 = sqrt(d2), l32 = (s32 - l30 * l20 - l31 * l21) / l22;
+                    const double d3 = s33 - l30 * l30 - l31 * l31 - l32 * l32, l33 = sqrt(d3);
+                    if (l == 0 && !(s00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0 && l33 < 1.0e300)) atomicMin(status, -6);   // RSLAM_ERR_NOT_SPD
+                    // row ln of the strip: its four entries sit in lanes ln, ln + 16, ln + 32, ln + 48 (register 0)
+                    const double q0 = __shfl(acc[0][0], ln), q1 = __shfl(acc[0][0], ln + 16), q2 = __shfl(acc[0][0], ln + 32), q3 = __shfl(acc[0][0], ln + 48);
+                    const double x0 = q0 / l00, x1 = (q1 - x0 * l10) / l11, x2 = (q2 - x0 * l20 - x1 * l21) / l22,
+                                 x3 = (q3 - x0 * l30 - x1 * l31 - x2 * l32) / l33;
+                    acc[0][0] = lq == 0 ? x0 : lq == 1 ? x1 : lq == 2 ? x2 : x3;
+                    if (xrows) {
+                        // K9 here: u^T = nu^T L^-T by the same substitution on the innovation row (every strip for itself: no hop)
+                        double nu4[4];
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            nu4[c4] = 0.0;
+                            if (c4 < r_total) { const int f = src.list[c4 >> 1]; nu4[c4] = src.z[2 * f + (c4 & 1)] - src.h[2 * f + (c4 & 1)]; }
+                        }
+                        const double u0 = nu4[0] / l00, u1 = (nu4[1] - u0 * l10) / l11, u2 = (nu4[2] - u0 * l20 - u1 * l21) / l22,
+                                     u3 = (nu4[3] - u0 * l30 - u1 * l31 - u2 * l32) / l33;
+                        const double xn = wk.x_in[first_row + ln] + (((x0 * u0 + x1 * u1) + x2 * u2) + x3 * u3);
+                        if (first_row != 0) {
+                            if (lq == 0) wk.x_out[first_row + ln] = xn;
+                        } else {
+                            double q[4] = { __shfl(xn, 3), __shfl(xn, 4), __shfl(xn, 5), __shfl(xn, 6) };
+                            if (lq == 0 && (ln < 3 || ln > 6)) wk.x_out[ln] = xn;
+                            if (l == 0) {
+                                quat_jnorm(q, wk.compat, wk.T);
+                                for (int i = 0; i < 4; ++i) wk.x_out[3 + i] = q[i];
+                                wait_stores();
+                                __hip_atomic_store(wk.xu_flag, wk.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
                 }
-                const double s00 = __shfl(v, 0), s10 = __shfl(v, 4), s11 = __shfl(v, 5), s20 = __shfl(v, 8), s21 = __shfl(v, 9),
-                             s22 = __shfl(v, 10), s30 = __shfl(v, 12), s31 = __shfl(v, 13), s32 = __shfl(v, 14), s33 = __shfl(v, 15);
-                const double l00 = sqrt(s00), l10 = s10 / l00, l20 = s20 / l00, l30 = s30 / l00;
-                const double d1 = s11 - l10 * l10, l11 = sqrt(d1), l21 = (s21 - l20 * l10) / l11, l31 = (s31 - l30 * l10) / l11;
-                const double d2 = s22 - l20 * l20 - l21 * l21, l22 = sqrt(d2), l32 = (s32 - l30 * l20 - l31 * l21) / l22;
-                const double d3 = s33 - l30 * l30 - l31 * l31 - l32 * l32, l33 = sqrt(d3);
-                if (l == 0 && !(s00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0 && l33 < 1.0e300)) atomicMin(status, -6);   // RSLAM_ERR_NOT_SPD
-                // row ln of the strip: its four entries sit in lanes ln, ln + 16, ln + 32, ln + 48 (register 0)
-                const double q0 = __shfl(acc[0][0], ln), q1 = __shfl(acc[0][0], ln + 16), q2 = __shfl(acc[0][0], ln + 32), q3 = __shfl(acc[0][0], ln + 48);
-                const double x0 = q0 / l00, x1 = (q1 - x0 * l10) / l11, x2 = (q2 - x0 * l20 - x1 * l21) / l22,
-                             x3 = (q3 - x0 * l30 - x1 * l31 - x2 * l32) / l33;
-                acc[0][0] = lq == 0 ? x0 : lq == 1 ? x1 : lq == 2 ? x2 : x3;
-            }
-            double* dst = Ypanel + 16L * strip + ln + (16L * w + lq) * ldA;
+                double* dst = Ypanel + 16L * strip + ln + (16L * w + lq) * ldA;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) dst[(4L * reg) * ldA] = (w == 0 && reg == 0) ? acc[0][0] : 0.0;
+                for (int reg = 0; reg < 4; ++reg) {
+                    const double v = (w == 0 && reg == 0) ? acc[0][0] : 0.0;
+                    if (fused) st_coh(dst + (4L * reg) * ldA, v); else dst[(4L * reg) * ldA] = v;
+                }
+            }
+            if (publish) {
+                wait_stores();
+                __syncthreads();
+                if (t == 0) __hip_atomic_store(&fl->y_flag[strip], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
         CdShared& sh = *reinterpret_cast<CdShared*>(lds);
@@ -1657,6 +1808,9 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
         }
         cd_factor_block<true>(sh, nullptr, ldA, 0, sel, slot_k, nullptr, status, 0, pre);
         double* Sk1 = lds + CDP_OFF_AOP;                     // behind CdShared
+        double* Xs1 = Sk1 + 64 * 16;                         // X in the layout of the general route ([64][16]), for the x update
+        abort = reinterpret_cast<int*>(Xs1 + 64 * 16 + 32 * 16 + 16);   // (the first location was inside CdShared)
+        if (t == 0) *abort = 0;
         if (g == 0) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Sk1[(16 * w + lq + 4 * reg) * 16 + ln] = acc[0][reg];
@@ -1669,14 +1823,36 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                 if (q < 4 * (w + 1)) x = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.Mf[(4 * q + lq) * CD_LD + 16 * w + ln], Sk1[(4 * q + lq) * 16 + ln], x, 0, 0, 0);
             double* dst = Ypanel + 16L * strip + ln + (16L * w + lq) * ldA;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) dst[(4L * reg) * ldA] = x[reg];
+            for (int reg = 0; reg < 4; ++reg) {
+                if (fused) st_coh(dst + (4L * reg) * ldA, x[reg]); else dst[(4L * reg) * ldA] = x[reg];
+                Xs1[(16 * w + lq + 4 * reg) * 16 + ln] = x[reg];
+            }
+        }
+        if (fused) {
+            wait_stores();
+            __syncthreads();
+            if (publish && t == 0) __hip_atomic_store(&fl->y_flag[strip], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (xrows) {
+                // one hop for u^T (this route is rare: a corrected-arithmetic LI set of at most 32 features)
+                if (sw_wait(&fl->y_flag[nu_strip], 1, status, abort, 8)) {
+                    xacc_add(xa, Xs1, uT, ldA, 0);
+                    xacc_finish(xa, first_row, wk, Xs1 + 64 * 16);
+                }
+            }
         }
         return;
     }
     static_for<0, NJ>([&](auto K) {
         constexpr int k = decltype(K)::value;
-        if (alive && k < nsteps) { sw_stamp(dbg, who, k, 0); alive = sw_wait(&fl->linv_ready, k + 1, status, abort, 1); sw_stamp(dbg, who, k, 1); }
         if (alive && k < nsteps) {
+            sw_stamp(dbg, who, k, 0);
+            // (P H^T strips of a fused launch also make sure u^T of the previous block is out: it has been for ~10 us)
+            if (xrows && k > 0) alive = sw_wait2(&fl->linv_ready, k + 1, &fl->y_flag[nu_strip], k, status, abort, 1);
+            else alive = sw_wait(&fl->linv_ready, k + 1, status, abort, 1);
+            sw_stamp(dbg, who, k, 1);
+        }
+        if (alive && k < nsteps) {
+            if (xrows && k > 0) xacc_add(xa, Xs, uT, ldA, k - 1);      // X of step k-1 is still in Xs (overwritten behind the next barrier)
             const bool mine = (g == (k & 1));                // this group holds column block k
             const double* Lk = Linv + 64L * 64 * k;
             // L^-1 rows 16 w .. 16 w + 15 are zero right of column 16 w + 15: 4 (w + 1) MFMA steps
@@ -1694,12 +1870,13 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                 for (int q = 0; q < 16; ++q)
                     if (q < 4 * (w + 1)) x = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], Sk[(4 * q + lq) * 16 + ln], x, 0, 0, 0);
                 // x[reg] = X(ln, 16 w + lq + 4 reg): final.  S rows: a panel block for the other strips; P H^T / nu rows: Y
-                // and u^T for the next kernel.  Both go to the second buffer: in the HI pass the rows of A below S are the
+                // and u^T for the next kernel -- or, in a fused launch, for the tile workers of this one (coherent stores +
+                // flag).  Both go to the second buffer: in the HI pass the rows of A below S are the
                 // P H^T that other strips may still be reading while they assemble their rows of S.
                 double* dst = Ypanel + 16L * strip + ln + (64L * k + 16 * w + lq) * ldA;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    if (is_s) st_coh(dst + (4L * reg) * ldA, x[reg]); else dst[(4L * reg) * ldA] = x[reg];
+                    if (is_s || fused) st_coh(dst + (4L * reg) * ldA, x[reg]); else dst[(4L * reg) * ldA] = x[reg];
                     Xs[(16 * w + lq + 4 * reg) * 16 + ln] = x[reg];
                 }
             }
@@ -1710,6 +1887,10 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                     __hip_atomic_fetch_add(&fl->row_cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(&fl->panel_cnt[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            } else if (fused) {
+                wait_stores();
+                __syncthreads();
+                if (publish && t == 0) __hip_atomic_store(&fl->y_flag[strip], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else __syncthreads();
             sw_stamp(dbg, who, k, 2);
             if (k < nupd) {
@@ -1768,6 +1949,13 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
             }
         }
     });
+    if (xrows && alive) {
+        // the last block's share of x + Y u (its X is still in Xs), then the strip's rows of x_k_k
+        if (sw_wait(&fl->y_flag[nu_strip], nblk, status, abort, 8)) {
+            xacc_add(xa, Xs, uT, ldA, nblk - 1);
+            xacc_finish(xa, first_row, wk, xscratch);
+        }
+    }
 }
 
 // ---- the chain workgroup of the persistent sweep ------------------------------------------------------------------
@@ -2084,27 +2272,298 @@ __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long
     }
 }
 
+
+// ---- the tile workers of the persistent sweep (fused launches) ---------------------------------------------------------
+// K10 + K11 without a launch of their own: P' = 1/2 (P + P^T) - Y Y^T (ExtendKF.cpp:608-609) and the Jnorm congruence
+// (:629-634) used to start when the whole sweep had ended, although column block k of Y is final right after step k.  The
+// workgroups the sweep does not need -- the launch is as large as the device, one workgroup per CU: the extra blocks behind
+// the strips, plus the strips that have no rows of this system -- each own up to WK_TILES lower-triangle tile pairs of P:
+// two four-wave MFMA engines (tile_gemm.h, LDS-DMA staging) in lockstep, WK_SLOTS tiles each, accumulators resident in
+// registers for the whole sweep.  The accumulators START as the symmetrised P tile and the A operand is negated (neg
+// modifier of the MFMA: free), so the epilogue has nothing left to read.  Per column block: poll the flag words of the
+// strips that hold the tiles' rows of Y, then two K = 32 chunks per tile, fetched with sc1 transfers (the strips' stores
+// are write-through: sweep_persistent_kernel, "Memory protocol").  Only the last block's chunks and the epilogue (tile,
+// Jnorm rows / columns, mirrored tile) are left when the pivot chain ends.  Nothing in the sweep waits for a worker.
+constexpr int WK_SLOTS = 3;
+constexpr int WK_TILES = 2 * WK_SLOTS;
+constexpr size_t WK_LDS_BYTES = sizeof(double) * 2 * TD_LDS_DOUBLES;
+static_assert(TD_LDS_DOUBLES >= TS_DOUBLES, "a worker engine's epilogue stages its tile in the operand buffers");
+
+struct WkTile { int bi, bj; bool have; };
+
+__device__ __forceinline__ WkTile wk_tile(const WorkerArgs& wk, int ti, int ntiles)
+{
+    WkTile r; r.bi = 0; r.bj = 0; r.have = ti < ntiles;
+    if (!r.have) return r;
+    if (wk.tile_order) { const int e = wk.tile_order[ti]; r.bi = e >> 16; r.bj = e & 0xffff; }
+    else {
+        int bi = (int)((sqrt(8.0 * (double)ti + 1.0) - 1.0) * 0.5);
+        while ((long)bi * (bi + 1) / 2 > ti) --bi;
+        while ((long)(bi + 1) * (bi + 2) / 2 <= ti) ++bi;
+        r.bi = bi; r.bj = ti - bi * (bi + 1) / 2;
+    }
+    return r;
+}
+
+// update() pass-through (no inliers, ExtendKF.cpp:635-638): every workgroup of the launch copies its share
+__device__ __forceinline__ void wk_passthrough(const WorkerArgs& wk, int NP)
+{
+    const int ntiles = wk.nT * (wk.nT + 1) / 2;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < NP; i += (int)(gridDim.x * blockDim.x)) wk.x_out[i] = wk.x_in[i];
+    if (wk.Pin == wk.Pout) return;
+    for (int ti = (int)blockIdx.x; ti < ntiles; ti += (int)gridDim.x) {
+        const WkTile tl = wk_tile(wk, ti, ntiles);
+        const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+        for (int c = g; c < 64; c += (int)(blockDim.x >> 6)) {
+            wk.Pout[64L * tl.bi + row + (64L * tl.bj + c) * wk.ldo] = wk.Pin[64L * tl.bi + row + (64L * tl.bj + c) * wk.ldp];
+            if (tl.bi != tl.bj) wk.Pout[64L * tl.bj + row + (64L * tl.bi + c) * wk.ldo] = wk.Pin[64L * tl.bj + row + (64L * tl.bi + c) * wk.ldp];
+        }
+    }
+}
+
+// one column block (NCH chunks of 32 columns) into the accumulators of this engine's tiles; n_wg slots are in use somewhere
+// in the workgroup (uniform), the engine's own tiles are tl[].have
+template <int NCH>
+__device__ __forceinline__ void wk_block(TgAcc (&acc)[WK_SLOTS], const WkTile (&tl)[WK_SLOTS], int n_wg, const double* __restrict__ Y, long ldy,
+                                         int kcol, double* hbase, int wave4)
+{
+    double* const Abuf[2] = { hbase, hbase + 2 * TD_OPER_DOUBLES };
+    double* const Bbuf[2] = { hbase + TD_OPER_DOUBLES, hbase + 3 * TD_OPER_DOUBLES };
+    const unsigned lo = td_lane_offset(ldy);
+    double a[TG_MI];
+    BFrag b[TG_NI];
+    if (tl[0].have) td_issue_chunk_w<16>(Y + 64L * tl[0].bi, ldy, Y + 64L * tl[0].bj, ldy, kcol, Abuf[0], Bbuf[0], wave4);
+    __syncthreads();                                      // (a barrier waits for this wave's transfers)
+    if (tl[0].have) td_read_frags(td_frag_ptr(Abuf[0], Bbuf[0], wave4), 0, a, b);
+    static_for<0, WK_SLOTS>([&](auto S) {
+        constexpr int slot = decltype(S)::value;
+        if (slot < n_wg) {
+            static_for<0, NCH>([&](auto C) {
+                constexpr int c = decltype(C)::value;
+                constexpr int u = slot * NCH + c, cur = u & 1, nxt = cur ^ 1;
+                constexpr int nslot = (c + 1 < NCH) ? slot : slot + 1, nc = (c + 1 < NCH) ? c + 1 : 0;
+                const bool more = (c + 1 < NCH) || (slot + 1 < n_wg);          // uniform over the workgroup
+                const bool nact = more && (nslot < WK_SLOTS) && tl[nslot < WK_SLOTS ? nslot : 0].have;
+                // source of the next chunk: the engine's own next tile, or -- when only the sibling engine has one -- anything valid
+                const WkTile& nt = tl[(nact && nslot < WK_SLOTS) ? nslot : 0];
+                const double* An = Y + 64L * nt.bi;
+                const double* Bn = Y + 64L * nt.bj;
+                const int kn = kcol + 32 * nc;
+                if (tl[slot].have) {
+                    if (more) td_compute_chunk_w<true, 16, 1>(Abuf[cur], Bbuf[cur], acc[slot], a, b, An, ldy, lo, Bn, ldy, lo, kn, Abuf[nxt], Bbuf[nxt], wave4);
+                    else      td_compute_chunk_w<false, 16, 1>(Abuf[cur], Bbuf[cur], acc[slot], a, b, An, ldy, lo, Bn, ldy, lo, kn, Abuf[nxt], Bbuf[nxt], wave4);
+                } else if (more) {
+                    if (nact) td_issue_chunk_w<16>(An, ldy, Bn, ldy, kn, Abuf[nxt], Bbuf[nxt], wave4);
+                    __syncthreads();
+                    if (nact) td_read_frags(td_frag_ptr(Abuf[nxt], Bbuf[nxt], wave4), 0, a, b);
+                }
+            });
+        }
+    });
+}
+
+__device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int r_total, int rp_blocks, long ldA, const double* Ypanel,
+                                                  const WorkerArgs& wk, SweepFlags* fl, const int32_t* __restrict__ sel, int slot_k,
+                                                  int32_t* status, double* lds, int* abort, unsigned long long* dbg)
+{
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), half = wave >> 2, wave4 = wave & 3;
+    const int lane = t & 63;
+    const int ntiles = wk.nT * (wk.nT + 1) / 2;
+    const int RP = 64 * rp_blocks;
+    if (t == 0) *abort = 0;
+    WkTile tl[WK_SLOTS];
+    int n_wg = 0;
+#pragma unroll
+    for (int slot = 0; slot < WK_SLOTS; ++slot) {
+        tl[slot] = wk_tile(wk, widx + (2 * slot + half) * W, ntiles);
+        if (widx + 2 * slot * W < ntiles) n_wg = slot + 1;            // (engine 0 has at least as many tiles as engine 1)
+    }
+    if (n_wg == 0) return;
+    const bool timing = dbg && widx == 0;
+    if (timing && t == 0) dbg[(5 * SWD_K + 0) * SWD_SLOT + 0] = wall_clock64();
+    // ---- accumulators = 1/2 (P + P^T) of the tile, in the MFMA result layout (tg_acc_to_lds): 128-byte row segments of
+    // both tiles of the pair.  The HI pass reads what the LI pass wrote -- mirrored pairs, exactly symmetric off the
+    // diagonal tiles -- so there the mirror tile need not be read.
+    const bool li_wrote = wk.li_done_slot >= 0 && sel[wk.li_done_slot] > 0;
+    TgAcc acc[WK_SLOTS];
+    {
+        const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+#pragma unroll
+        for (int slot = 0; slot < WK_SLOTS; ++slot) {
+            tg_zero(acc[slot]);
+            if (!tl[slot].have) continue;
+            const bool mirror_known = li_wrote && tl[slot].bi != tl[slot].bj;
+            const double* Pij = wk.Pin + 64L * tl[slot].bi + 64L * tl[slot].bj * wk.ldp;
+            const double* Pji = wk.Pin + 64L * tl[slot].bj + 64L * tl[slot].bi * wk.ldp;
+#pragma unroll
+            for (int mi = 0; mi < TG_MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = mi * 16 + 4 * blk + i, col = wave4 * 16 + 4 * ((blk - q) & 3) + j;
+                    const double pij = Pij[row + (long)col * wk.ldp];
+                    acc[slot][mi][0][q] = mirror_known ? pij : 0.5 * pij + 0.5 * Pji[col + (long)row * wk.ldp];
+                }
+        }
+    }
+    // ---- the strips whose flag words this workgroup polls: lane = (tile, operand, strip of the 64-row block)
+    int my_flag = -1;
+    if (t < 8 * WK_TILES) {
+        const int s6 = t >> 3, sub = t & 7;                          // tile s6 = 2 slot + engine
+        const WkTile tt = wk_tile(wk, widx + s6 * W, ntiles);
+        if (tt.have) my_flag = 4 * rp_blocks + 4 * (sub < 4 ? tt.bi : tt.bj) + (sub & 3);
+    }
+    double* hbase = lds + (size_t)half * TD_LDS_DOUBLES;
+    const double* Y = Ypanel + RP;
+    for (int k = 0; k < nblk; ++k) {
+        if (timing && t == 0 && k < SWD_K) dbg[(5 * SWD_K + k) * SWD_SLOT + 1] = wall_clock64();
+        if (t < 64) {
+            int spins = 0;
+            while (true) {
+                const int v = my_flag >= 0 ? ld_flag(&fl->y_flag[my_flag]) : k + 1;
+                if (__all(v >= k + 1)) break;
+                if (++spins > SW_SPIN_LIMIT) { if (t == 0) { atomicMin(status, -37); *abort = 1; } break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        if (*abort) return;                                          // the host re-runs the update stage: nothing is written
+        if (timing && t == 0 && k < SWD_K) dbg[(5 * SWD_K + k) * SWD_SLOT + 2] = wall_clock64();
+        const int r_here = r_total - 64 * k;
+        if (r_here > 32) wk_block<2>(acc, tl, n_wg, Y, ldA, 64 * k, hbase, wave4);
+        else             wk_block<1>(acc, tl, n_wg, Y, ldA, 64 * k, hbase, wave4);
+        if (timing && t == 0 && k < SWD_K) dbg[(5 * SWD_K + k) * SWD_SLOT + 3] = wall_clock64();
+    }
+    // ---- epilogue per tile: through LDS (coalesced stores of the tile and of its mirror); K11 on the first block column
+    const int t4 = t & 255, row = t4 & 63, g4 = t4 >> 6;
+    double* Cs = hbase;
+    const bool k11 = wk.T && sel[slot_k] != 0;
+    static_for<0, WK_SLOTS>([&](auto S) {
+        constexpr int slot = decltype(S)::value;
+        if (slot < n_wg) {
+            const bool have = tl[slot].have;
+            const int bi = tl[slot].bi, bj = tl[slot].bj;
+            __syncthreads();                                         // the operand buffers / the previous tile's image are free
+            if (have) tg_acc_to_lds_w(acc[slot], Cs, 1.0, wave4);
+            __syncthreads();
+            if (have && k11 && bj == 0 && t4 < 64) {
+                // Jnorm comes from the strip of state rows 0..15 of this launch (xacc_finish), long ago
+                int spins = 0;
+                while (ld_flag(wk.xu_flag) < wk.token) {
+                    if (++spins > (1 << 22)) { atomicMin(status, -38); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                double T[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) T[q] = ld_coh(wk.T + q);
+                const int j = t4;
+                if (bi != 0) {
+                    double rb[4];
+                    for (int i = 0; i < 4; ++i) {
+                        double sacc = 0;
+                        for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[(3 + q) * TS_LD + j];   // P(3+q, col) by symmetry
+                        rb[i] = sacc;
+                    }
+                    for (int i = 0; i < 4; ++i) Cs[(3 + i) * TS_LD + j] = rb[i];
+                } else if (!(j >= 3 && j < 7)) {
+                    double rb[4];
+                    for (int i = 0; i < 4; ++i) {
+                        double sacc = 0;
+                        for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[j * TS_LD + (3 + q)];
+                        rb[i] = sacc;
+                    }
+                    for (int i = 0; i < 4; ++i) { Cs[j * TS_LD + (3 + i)] = rb[i]; Cs[(3 + i) * TS_LD + j] = rb[i]; }
+                } else if (j == 3) {
+                    double cb[4][4], out[4][4];         // cb = J * P44 ; out = cb * J^T
+                    for (int i = 0; i < 4; ++i)
+                        for (int c = 0; c < 4; ++c) {
+                            double sacc = 0;
+                            for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[(3 + c) * TS_LD + (3 + q)];
+                            cb[i][c] = sacc;
+                        }
+                    for (int i = 0; i < 4; ++i)
+                        for (int c = 0; c < 4; ++c) {
+                            double sacc = 0;
+                            for (int q = 0; q < 4; ++q) sacc += cb[i][q] * T[c + 4 * q];
+                            out[i][c] = sacc;
+                        }
+                    for (int i = 0; i < 4; ++i)
+                        for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = out[i][c];
+                }
+            }
+            __syncthreads();
+            if (have) {
+                double* Cij = wk.Pout + 64L * bi + 64L * bj * wk.ldo;
+                double* Cji = wk.Pout + 64L * bj + 64L * bi * wk.ldo;
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    const int c = g4 + 4 * q;
+                    Cij[row + (long)c * wk.ldo] = Cs[c * TS_LD + row];
+                }
+                if (bi != bj) {
+#pragma unroll 4
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = g4 + 4 * q;
+                        Cji[row + (long)c * wk.ldo] = Cs[row * TS_LD + c];
+                    }
+                }
+            }
+        }
+    });
+    if (timing && t == 0) dbg[(5 * SWD_K + 0) * SWD_SLOT + 4] = wall_clock64();
+}
+
 template <int NJ>
 __global__ void __launch_bounds__(CD_THREADS)
 sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, int slot_nblk, int slot_k, int rp_blocks, int NP,
                         SysSrc src, double* Linv, double* Ypanel, int32_t* flags, int32_t* flags_other, int32_t* status,
-                        unsigned long long* dbg, int exp_mask)
+                        unsigned long long* dbg, int exp_mask, WorkerArgs wk)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int s_wk_abort;
     // The hand-over flags are double-buffered between the two sweeps of a frame: this launch uses `flags` (all zero:
     // the previous sweep cleared them) and clears `flags_other` for the next one -- nobody is using that set now.
     if (blockIdx.x == 0 && threadIdx.x < SWEEP_FLAG_INTS) flags_other[threadIdx.x] = 0;
     SweepFlags* fl = reinterpret_cast<SweepFlags*>(flags);
+    const bool fused = wk.Pout != nullptr;
     int nblk = sel[slot_nblk];
     if (nblk > rp_blocks) nblk = rp_blocks;
-    if (nblk <= 0) return;
+    if (nblk <= 0) {                                          // no inliers: update() is the identity (ExtendKF.cpp:635-638)
+        if (fused) wk_passthrough(wk, NP);
+        return;
+    }
     const int r_total = 2 * sel[slot_k];
     const bool single = (nblk == 1) && !(exp_mask & 4);       // one diagonal block: every strip factors it itself, no chain workgroup
-    if (blockIdx.x != 0) sweep_strip<NJ>(A, ldA, rp_blocks, nblk, (int)blockIdx.x - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k, (exp_mask & 8) != 0);
-    else if (single) return;
-    else if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, NP / 16 + 1);
-    // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
-    //  been scheduled: every strip must run into its bounded wait and the host must recover the frame)
+    const int nstrips = (int)(ldA / 16);
+    const int bx = (int)blockIdx.x;
+    if (bx == 0) {
+        if (single) return;
+        // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
+        //  been scheduled: every strip must run into its bounded wait and the host must recover the frame)
+        if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, NP / 16 + 1);
+        return;
+    }
+    int widx = -1;                                            // tile worker index, or -1: this workgroup is a strip of the system
+    if (fused) {
+        // Workers: the blocks behind the strips, and the strips that hold no rows of this system -- S row blocks 0, 1 (the
+        // lower strips assemble those for the chain) and nblk .. (padding), and the three strips below nu^T.
+        const int extra = (int)gridDim.x - 1 - nstrips;
+        const int lo_blocks = rp_blocks < 2 ? rp_blocks : 2, hi0 = nblk > 2 ? nblk : 2;
+        const int n_idle_s = 4 * (lo_blocks + (rp_blocks > hi0 ? rp_blocks - hi0 : 0));
+        if (bx > nstrips) widx = bx - 1 - nstrips;
+        else {
+            const int strip = bx - 1, b = strip >> 2;
+            if (b < rp_blocks) { if (b < 2) widx = extra + strip; else if (b >= hi0) widx = extra + 4 * lo_blocks + (strip - 4 * hi0); }
+            else if (b == (int)(ldA / 64) - 1 && (strip & 3) != 0) widx = extra + n_idle_s + (strip & 3) - 1;
+        }
+        if (widx >= 0) {
+            sweep_tile_worker(widx, extra + n_idle_s + 3, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg);
+            return;
+        }
+    }
+    if (bx <= nstrips)
+        sweep_strip<NJ>(A, ldA, rp_blocks, nblk, bx - 1, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k,
+                        (exp_mask & 8) != 0, wk, exp_mask);
 }
 
 // dynamic LDS of the kernels that factor a diagonal block (the fused one also runs tile products in it)
@@ -2175,16 +2634,33 @@ int sweep_exp_mask()
     return g_sweep_exp_override >= 0 ? g_sweep_exp_override : env;
 }
 
-bool sweep_persistent_eligible(const SystemDims& d)
+static int device_cus()
 {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0; hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
     }
+    return cus;
+}
+
+bool sweep_persistent_eligible(const SystemDims& d)
+{
     static const bool off = getenv("RSLAM_SWEEP_STEPS") != nullptr;       // measurement: the one-launch-per-step sequence
     if (off || d.RP <= 0) return false;
-    return d.RP / 64 <= 16 && 1 + d.ldA / 16 <= cus;
+    return d.RP / 64 <= 16 && 1 + d.ldA / 16 <= device_cus();
+}
+
+// The x and covariance update ride inside the persistent sweep when the workgroups it leaves idle -- the launch is as large
+// as the device -- can hold every lower-triangle tile pair of P in their accumulators (WK_TILES each), whatever the inlier
+// count turns out to be (fewest workers: every S row block in use).
+bool sweep_fused_eligible(const SystemDims& d)
+{
+    static const bool off = getenv("RSLAM_SWEEP_UNFUSED_K10") != nullptr;  // measurement: rank update as a launch of its own
+    if (off || !sweep_persistent_eligible(d)) return false;
+    const int rp_blocks = d.RP / 64, nT = d.NP / 64;
+    const int workers = device_cus() - 1 - d.ldA / 16 + 4 * (rp_blocks < 2 ? rp_blocks : 2) + 3;
+    return (long)nT * (nT + 1) / 2 <= (long)WK_TILES * workers;
 }
 
 // One stream: diag(0), then ONE launch per block step (sweep_step_kernel); for large systems (more than 512 tile
@@ -2197,7 +2673,7 @@ bool sweep_persistent_eligible(const SystemDims& d)
 // sequence, A itself for the others.
 double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
                             const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
-                            int32_t* status_sel, int32_t* flags, const SysSrc* src)
+                            int32_t* status_sel, int32_t* flags, const SysSrc* src, const WorkerArgs* wk)
 {
     const int rp_blocks = d.RP / 64;
     const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
@@ -2208,12 +2684,15 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
     if (!two && !unfused && flags && src && sweep_persistent_eligible(d)) {
         // one launch for the whole sweep, sized for the largest inlier count the frame can have: the launch sequence
         // never depends on the previous frame (cap_blocks is not used)
-        const dim3 grid(1 + d.ldA / 16), block(CD_THREADS);
+        WorkerArgs wa{};                                   // Pout == nullptr: the caller launches the rank update itself
+        if (wk && wk->Pout && sweep_fused_eligible(d)) wa = *wk;
+        // fused: one workgroup per compute unit -- the ones behind the strips are tile workers
+        const dim3 grid(wa.Pout ? device_cus() : 1 + d.ldA / 16), block(CD_THREADS);
         const int exp_mask = sweep_exp_mask();             // measurement / fault-injection switches
         const int set = (slot_k == SEL_K_LI) ? 0 : 1;              // the LI and the HI sweep of a frame alternate between the two flag sets
         int32_t* fl_cur = flags + set * SWEEP_FLAG_INTS;
         int32_t* fl_other = flags + (1 - set) * SWEEP_FLAG_INTS;
-#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, g_sweep_dbg, exp_mask)
+#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, g_sweep_dbg, exp_mask, wa)
         if (rp_blocks <= 4) SWP_LAUNCH(4);
         else if (rp_blocks <= 8) SWP_LAUNCH(8);
         else if (rp_blocks <= 12) SWP_LAUNCH(12);

@@ -478,6 +478,18 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
                               Wsrc, c->d_rank_of.p, nullptr);
     if (ev_f0 >= 0) mark(c, ev_f0);
     const double* Ysys = c->d_A.p;        // the system whose lower rows hold Y = P H^T L^-T and u^T after the sweep
+    // K9 / K10 / K11 ride INSIDE the persistent sweep launch when the compute units it leaves idle can hold every tile pair
+    // of P (kernels.hip, "tile workers"): the rank update then runs under the pivot chain instead of behind it.
+    const bool fused = persistent && sweep_fused_eligible(d);
+    const int32_t* order = (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr;
+    WorkerArgs wk{};
+    if (fused) {
+        wk.Pin = Pin; wk.ldp = c->NP; wk.Pout = Pout; wk.ldo = c->NP; wk.tile_order = order; wk.nT = c->NP / 64;
+        wk.x_in = x_in; wk.x_out = x_out; wk.T = c->d_T.p; wk.compat = c->cfg.compat;
+        wk.token = (slot_k == SEL_K_LI) ? 1 : 2;          // sel[] is zeroed at the start of a frame (predict_kernel)
+        wk.xu_flag = sel + SEL_XU_FLAG;
+        wk.li_done_slot = (slot_k == SEL_K_HI) ? SEL_NBLK_LI : -1;
+    }
     {
         static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // two-stream variant, measured slower: off
         const size_t need = 2 * (size_t)(c->RP / 64 + 1);
@@ -489,19 +501,21 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
         Ysys = launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk,
                                    cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
-                                   persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr);
+                                   persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr, fused ? &wk : nullptr);
     }
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP <= 0) HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
     if (ev_r0 >= 0) mark(c, ev_r0);
-    // K9 (x_k_k = x + Y u, quaternion normalisation, Jnorm) rides in the rank-update launch
-    XuArgs xu{};
-    xu.groups = c->RP > 0 ? c->NP / 16 : 0;
-    xu.d = d; xu.A = Ysys; xu.x_in = x_in; xu.x_out = x_out; xu.T = c->d_T.p; xu.compat = c->cfg.compat;
-    xu.token = (slot_k == SEL_K_LI) ? 1 : 2;              // sel[] is zeroed at the start of a frame (predict_kernel)
-    xu.flag = sel + SEL_XU_FLAG;
-    launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
-                       (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr, c->RP > 0 ? c->d_T.p : nullptr, slot_k, &xu);
+    if (!fused) {
+        // K9 (x_k_k = x + Y u, quaternion normalisation, Jnorm) rides in the rank-update launch
+        XuArgs xu{};
+        xu.groups = c->RP > 0 ? c->NP / 16 : 0;
+        xu.d = d; xu.A = Ysys; xu.x_in = x_in; xu.x_out = x_out; xu.T = c->d_T.p; xu.compat = c->cfg.compat;
+        xu.token = (slot_k == SEL_K_LI) ? 1 : 2;              // sel[] is zeroed at the start of a frame (predict_kernel)
+        xu.flag = sel + SEL_XU_FLAG;
+        launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
+                           order, c->RP > 0 ? c->d_T.p : nullptr, slot_k, &xu);
+    }
     if (ev_r1 >= 0) mark(c, ev_r1);
     return RSLAM_OK;
 }
@@ -1378,6 +1392,42 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
     launch_mfma4_raw(c->stream, cbsz, abid, p, p + 64, p + 128, p + 192);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(d, p + 192, 512, hipMemcpyDeviceToHost));
+    return RSLAM_OK;
+}
+
+// diagnostics (not part of include/rslam.h) behind the value-level tests of the scoring arithmetic (tests/test_gpu_scoring.py):
+// the squared residuals score_kernel compares with sigma_z^2, for every hypothesised position of the resident frame
+// (out: host, m * m, row = matched rank of the hypothesised feature); needs a frame whose scoring stage has been enqueued
+extern "C" int rslam_debug_score_residuals(rslam_ctx* c, double* out, int32_t* m_out)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    if (m_out) *m_out = c->m;
+    if (!out) return RSLAM_OK;
+    if (!c->predicted || !c->have_meas || !c->pht_done) return RSLAM_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const int m = c->m;
+    if (m == 0) return RSLAM_OK;
+    if (c->d_probe.ensure((size_t)m * m) < 0) return RSLAM_ERR_HIP;
+    launch_score_residuals(c->stream, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, m, c->d_probe.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->d_probe.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RSLAM_OK;
+}
+
+// distort_fm_score (scoring kernel) and distort_fm (everything else; the reference's ten Newton steps) on n undistorted pixels
+extern "C" int rslam_debug_distort(rslam_ctx* c, int32_t n, const double* uv, double* out_score, double* out_ref)
+{
+    if (!c || n <= 0 || !uv || !out_score || !out_ref) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_probe.ensure((size_t)6 * n) < 0) return RSLAM_ERR_HIP;
+    double* d = c->d_probe.p;
+    HIPCHK(hipMemcpyAsync(d, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    launch_distort_probe(c->stream, c->cam, n, d, d + 2 * (size_t)n, d + 4 * (size_t)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_score, d + 2 * (size_t)n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out_ref, d + 4 * (size_t)n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return RSLAM_OK;
 }
 

@@ -109,12 +109,14 @@ __device__ __forceinline__ BFrag tg_rotations(double b)
 
 // acc[t] accumulates, for lane (i = l>>4, blk = (l>>2)&3, j = l&3), the element
 //   row 4*blk + i,  column 4*((blk - t) & 3) + j   of a 16 x 16 tile.
+// NEGA: acc -= a b (for f64 MFMAs the BLGP field of the instruction is the neg:[a,b,c] modifier: free)
+template <int NEGA = 0>
 __device__ __forceinline__ void tg_mma_16x16x4(double a, const BFrag& b, d4& acc)
 {
-    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r1, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r2, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r3, acc[3], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r0, acc[0], 0, 0, NEGA);
+    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r1, acc[1], 0, 0, NEGA);
+    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r2, acc[2], 0, 0, NEGA);
+    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.r3, acc[3], 0, 0, NEGA);
 }
 
 // One staged K chunk.  Software pipelined by hand: the fragments of k-step s+1 are read
@@ -248,37 +250,48 @@ __device__ __forceinline__ unsigned td_lane_offset(long ld)
 }
 
 // segment sg (k-step sg >> 1, parity sg & 1) of the chunk that starts at column k0, both operands
+// AUX: cache policy of the transfers (16 = sc1: operands another workgroup of the same launch has just published)
+template <int AUX = 0>
 __device__ __forceinline__ void td_issue_seg(const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
                                              int k0, int sg, double* As, double* Bs)
 {
     const long ku = k0 + 4 * (sg >> 1) + (sg & 1);        // wave-uniform
     const char* ga = reinterpret_cast<const char*>(A + ku * lda) + la;
     const char* gb = reinterpret_cast<const char*>(B + ku * ldb) + lb;
-    __builtin_amdgcn_global_load_lds((tg_glb_void*)ga, (tg_lds_void*)(As + sg * TD_SEG), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((tg_glb_void*)gb, (tg_lds_void*)(Bs + sg * TD_SEG), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((tg_glb_void*)ga, (tg_lds_void*)(As + sg * TD_SEG), 16, 0, AUX);
+    __builtin_amdgcn_global_load_lds((tg_glb_void*)gb, (tg_lds_void*)(Bs + sg * TD_SEG), 16, 0, AUX);
 }
 
 // chunk k0 .. k0 + TG_KC of both operands -> LDS images As, Bs; four segments per wave and operand
+// (wave: index 0..3 of the wave inside its four-wave engine)
+template <int AUX = 0>
+__device__ __forceinline__ void td_issue_chunk_w(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                 int k0, double* As, double* Bs, int wave)
+{
+    const unsigned la = td_lane_offset(lda), lb = td_lane_offset(ldb);
+#pragma unroll
+    for (int q = 0; q < TG_KC / 8; ++q) td_issue_seg<AUX>(A, lda, la, B, ldb, lb, k0, wave + 4 * q, As, Bs);
+}
 __device__ __forceinline__ void td_issue_chunk(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                int k0, double* As, double* Bs)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned la = td_lane_offset(lda), lb = td_lane_offset(ldb);
-#pragma unroll
-    for (int q = 0; q < TG_KC / 8; ++q) td_issue_seg(A, lda, la, B, ldb, lb, k0, wave + 4 * q, As, Bs);
+    td_issue_chunk_w<0>(A, lda, B, ldb, k0, As, Bs, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 // Fragment read addresses of a wave inside an operand image (k-step 0; k-step s is TD_STEP * s further)
 struct TdFragPtr { const double* a; const double* b0; const double* b1; const double* b2; const double* b3; };
-__device__ __forceinline__ TdFragPtr td_frag_ptr(const double* As, const double* Bs)
+__device__ __forceinline__ TdFragPtr td_frag_ptr(const double* As, const double* Bs, int wave)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / TG_WN, wn = wave % TG_WN;
     const int kq = lane >> 4, ij = lane & 15;
     const int koff = (kq & 1) * TD_SEG + (kq >> 1) * 64;
     const double* bb = Bs + koff + wn * 16 * TG_NI;
     return TdFragPtr{ As + koff + wm * 16 * TG_MI + ij, bb + ij, bb + ((ij - 4) & 15), bb + ((ij - 8) & 15), bb + ((ij - 12) & 15) };
+}
+__device__ __forceinline__ TdFragPtr td_frag_ptr(const double* As, const double* Bs)
+{
+    return td_frag_ptr(As, Bs, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 __device__ __forceinline__ void td_read_frags(const TdFragPtr& p, int o, double (&a)[TG_MI], BFrag (&b)[TG_NI])
 {
@@ -297,31 +310,34 @@ __device__ __forceinline__ void td_read_frags(const TdFragPtr& p, int o, double 
 //    chunk barrier sits BEFORE the MFMAs of the last k-step: the first fragments of the next chunk are read under them,
 //    so no wave starts a chunk with an exposed LDS round trip.  (The other buffer is free again when every wave has
 //    passed that barrier: its last reads were waited for in front of it.)
-template <bool NEXT>
-__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc, double (&a)[TG_MI], BFrag (&b)[TG_NI],
-                                                 const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
-                                                 int k0n, double* An, double* Bn)
+//  * wave: index 0..3 inside the four-wave engine (two engines share a 512-thread workgroup in the factor sweep's tile
+//    workers); AUX: cache policy of the transfers; NEGA: acc -= A B^T.  (No run-time switch for the transfers: a branch
+//    inside the k loop would split the scheduling region the pinned order lives in.  An engine that has no next chunk of
+//    its own while its sibling has one passes any valid source.)
+template <bool NEXT, int AUX = 0, int NEGA = 0>
+__device__ __forceinline__ void td_compute_chunk_w(const double* As, const double* Bs, TgAcc& acc, double (&a)[TG_MI], BFrag (&b)[TG_NI],
+                                                   const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
+                                                   int k0n, double* An, double* Bn, int wave)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const TdFragPtr cur = td_frag_ptr(As, Bs);
+    const TdFragPtr cur = td_frag_ptr(As, Bs, wave);
 #pragma unroll
     for (int kk = 0; kk < TG_KC; kk += 4) {
         double na[TG_MI];
         BFrag nb[TG_NI];
         const bool dma = NEXT && (kk / 4 < TG_KC / 8);
         const bool last = (kk + 4 >= TG_KC);
-        if (dma) td_issue_seg(A, lda, la, B, ldb, lb, k0n, wave + 4 * (kk / 4), An, Bn);
+        if (dma) td_issue_seg<AUX>(A, lda, la, B, ldb, lb, k0n, wave + 4 * (kk / 4), An, Bn);
         if (!last) {
             td_read_frags(cur, (kk / 4 + 1) * TD_STEP, na, nb);
         } else if (NEXT) {
             __syncthreads();                                // next chunk landed (vmcnt(0) in front of the barrier), this one read
             __builtin_amdgcn_sched_barrier(0);
-            td_read_frags(td_frag_ptr(An, Bn), 0, na, nb);
+            td_read_frags(td_frag_ptr(An, Bn, wave), 0, na, nb);
         }
 #pragma unroll
         for (int mi = 0; mi < TG_MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TG_NI; ++ni) tg_mma_16x16x4(a[mi], b[ni], acc[mi][ni]);
+            for (int ni = 0; ni < TG_NI; ++ni) tg_mma_16x16x4<NEGA>(a[mi], b[ni], acc[mi][ni]);
         if (dma) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // the two transfers
         if (!last || NEXT) {
 #pragma unroll
@@ -340,6 +356,14 @@ __device__ __forceinline__ void td_compute_chunk(const double* As, const double*
             for (int ni = 0; ni < TG_NI; ++ni) b[ni] = nb[ni];
         }
     }
+}
+
+template <bool NEXT>
+__device__ __forceinline__ void td_compute_chunk(const double* As, const double* Bs, TgAcc& acc, double (&a)[TG_MI], BFrag (&b)[TG_NI],
+                                                 const double* __restrict__ A, long lda, unsigned la, const double* __restrict__ B, long ldb, unsigned lb,
+                                                 int k0n, double* An, double* Bn)
+{
+    td_compute_chunk_w<NEXT, 0, 0>(As, Bs, acc, a, b, A, lda, la, B, ldb, lb, k0n, An, Bn, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 // acc += A(64 x K) * B(64 x K)^T, LDS-DMA staged.  lds holds TD_LDS_DOUBLES.  Ends with a barrier.
@@ -384,10 +408,9 @@ static_assert(TG_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 til
 static_assert(TD_LDS_DOUBLES >= 2 * TS_DOUBLES, "epilogues stage two 64 x 65 tiles in the operand buffers");
 
 template <int LD = 65>
-__device__ __forceinline__ void tg_acc_to_lds(const TgAcc& acc, double* Cs, double scale)
+__device__ __forceinline__ void tg_acc_to_lds_w(const TgAcc& acc, double* Cs, double scale, int wave)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int wm = wave / TG_WN, wn = wave % TG_WN;
     const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
 #pragma unroll
@@ -400,6 +423,11 @@ __device__ __forceinline__ void tg_acc_to_lds(const TgAcc& acc, double* Cs, doub
                 const int col = (wn * TG_NI + ni) * 16 + 4 * ((blk - t) & 3) + j;
                 Cs[col * LD + row] = acc[mi][ni][t] * scale;
             }
+}
+template <int LD = 65>
+__device__ __forceinline__ void tg_acc_to_lds(const TgAcc& acc, double* Cs, double scale)
+{
+    tg_acc_to_lds_w<LD>(acc, Cs, scale, (int)(threadIdx.x >> 6));
 }
 
 // A 64 x 64 operand from global memory into two consecutive operand buffers (k = 0..31, 32..63).

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_slam_amd import api, default_config           # noqa: E402
 from ransac_slam_amd.synth import make_frame              # noqa: E402
 
-WHO, K, SLOT = 5, 16, 8
+WHO, K, SLOT = 6, 16, 8
 ap = argparse.ArgumentParser()
 ap.add_argument("--compat", type=int, default=1)
 ap.add_argument("--L", type=int, default=300)
@@ -50,3 +50,8 @@ for who in (1, 2, 3, 4):
         if st[who, k, 0] == 0:
             break
         print(f"  step {k:2d}: " + " ".join(f"{us(v):8.2f}" for v in st[who, k, :6]))
+print("tile worker 0 (fused launches): start %.2f, epilogue done %.2f; per block [wait begins, Y flags seen, chunks done]" % (us(st[5, 0, 0]), us(st[5, 0, 4])))
+for k in range(K):
+    if st[5, k, 1] == 0:
+        break
+    print(f"  block {k:2d}: " + " ".join(f"{us(v):8.2f}" for v in st[5, k, 1:4]))
