@@ -378,6 +378,29 @@ class RslamHip:
         _chk(lib().rslam_k_mfma4_raw(self._h, cbsz, abid, _p(a), _p(b), _p(c), _p(d)), "rslam_k_mfma4_raw")
         return d
 
+    # ---- diagnostics (not part of include/rslam.h) ---------------------------
+    def debug_score_residuals(self):
+        """(m, m) squared residuals the scoring kernel compares with sigma_z^2: row = matched rank of the hypothesised
+        feature, column = matched rank of the scored one (resident frame, after its scoring stage ran)"""
+        fn = lib().rslam_debug_score_residuals
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, _dp, _i32p]
+        m = C.c_int32()
+        _chk(fn(self._h, None, C.byref(m)), "rslam_debug_score_residuals")
+        out = np.zeros((max(m.value, 1), max(m.value, 1)))
+        _chk(fn(self._h, _p(out), C.byref(m)), "rslam_debug_score_residuals")
+        return out[:m.value, :m.value]
+
+    def debug_distort(self, uv):
+        """undistorted pixels (n, 2) -> (distort_fm_score, distort_fm) as the device evaluates them"""
+        fn = lib().rslam_debug_distort
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        a = np.zeros_like(uv); b = np.zeros_like(uv)
+        _chk(fn(self._h, len(uv), _p(uv), _p(a), _p(b)), "rslam_debug_distort")
+        return a, b
+
     def hbm_copy_peak(self, nbytes=1 << 30):
         v = C.c_double()
         _chk(lib().rslam_k_hbm_copy_peak(self._h, nbytes, C.byref(v)), "rslam_k_hbm_copy_peak")

@@ -15,6 +15,7 @@ struct Cam {
     double k1, k2, Cx, Cy, f, dx, dy;
     int nRows, nCols;
     double inv_dx, inv_dy, f_ku;     // 1/dx, 1/dy, f * (1/dx): correctly rounded on the host once (scoring kernel)
+    double ru2_fast;                 // squared undistorted radius up to which distort_fm_score's six steps have converged (host)
 };
 
 // ExtendKF::q2r (src/ExtendKF.cpp:91-102); q = (r,x,y,z); R column-major.
@@ -71,22 +72,30 @@ __device__ __forceinline__ double rcp_nr2(double d)
     return r;
 }
 
+__device__ __forceinline__ void distort_fm(const Cam& cam, double u, double v, double& ud, double& vd);
+
 // distort_fm for the hypothesis scoring (Tracking.cpp:472-476 only compares the result with a threshold; the decisions
-// are audited for a 1e-9 margin, the values need not be bit-identical to a divide-based evaluation).  The reference's
-// 10 Newton steps divide by the slope f'(rd); any factor within 2^-26 of 1/f' gives the same fixed point -- the error of
-// step n+1 is eps * (error of step n) + O(error^2) -- so the slope reciprocal is the raw v_rcp_f64.  The divisions that
-// enter the result (1/D, 1/dx, 1/dy) are full-precision reciprocals (dx, dy: from the host).
+// are audited for a 1e-9 margin, the values need not be bit-identical to a divide-based evaluation -- they agree with it to
+// ~1e-13 px, tests/test_gpu_scoring.py).  The reference's 10 Newton steps (ExtendKF.cpp:186-200) divide by the slope f'(rd);
+// any factor within 2^-26 of 1/f' gives the same fixed point -- the error of step n+1 is eps * (error of step n) +
+// O(error^2) -- so the slope reciprocal is the raw v_rcp_f64.  The divisions that enter the result (1/D, 1/dx, 1/dy) are
+// full-precision reciprocals (dx, dy: from the host).
+// Six steps instead of ten: the starting point ru / (1 + k1 ru^2 + k2 ru^4) is ~25 % low at the image corner (ru = 2.3 mm
+// with the reference's camera) and the steps converge quadratically from there: at ru <= cam.ru2_fast^(1/2) -- found on the
+// host by running this very iteration, ~1.5 corner radii -- six steps are at the fixed point to < 1e-13 relative.  Beyond
+// that radius (projections far outside the image: a hypothesis that puts a feature almost in the image plane) neither six nor
+// ten steps need to have converged, the NON-converged ten-step value is what the reference compares -- it can even land back
+// inside the image -- so those pairs take the reference's own sequence (distort_fm below: ten steps, IEEE divisions).
 __device__ __forceinline__ void distort_fm_score(const Cam& cam, double u, double v, double& ud, double& vd)
 {
     const double xu = (u - cam.Cx) * cam.dx;
     const double yu = (v - cam.Cy) * cam.dy;
-    const double ru = sqrt(xu * xu + yu * yu);
-    const double ru2 = ru * ru;
+    const double ru2 = xu * xu + yu * yu;
+    if (!(ru2 <= cam.ru2_fast)) { distort_fm(cam, u, v, ud, vd); return; }      // (also NaN / inf)
+    const double ru = sqrt(ru2);
     double rd = ru * __builtin_amdgcn_rcp(1 + cam.k1 * ru2 + cam.k2 * (ru2 * ru2));     // starting point only
     const double k1_3 = 3 * cam.k1, k2_5 = 5 * cam.k2;
 #pragma unroll
-    // Six steps reach the fixed point the reference's ten reach: the starting point is within ~1e-2 relative, the steps
-    // converge quadratically (1e-4, 1e-8, ...) until the 2^-26 slope error makes them linear with that factor.
     for (int k = 0; k < 6; ++k) {
         const double rd2 = rd * rd, rd4 = rd2 * rd2;
         const double f = rd + cam.k1 * (rd2 * rd) + cam.k2 * (rd4 * rd) - ru;

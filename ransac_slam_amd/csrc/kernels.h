@@ -15,6 +15,7 @@ enum SelSlot {
     SEL_CAP_FLAG = 9,        // != 0: the captured launch sequence of a factor sweep was shorter than the inlier count
                              // needs; the host re-runs the update stage with the full-length sequence
     SEL_STATUS_FRONT = 10,   // status of the prediction / scoring stage (kept when only the update stage is re-run)
+    SEL_STICKY = 11,         // smallest status of the frames whose status word the next frame's reset has overwritten unread
     SEL_COUNT = 16
 };
 
@@ -112,6 +113,8 @@ struct XuArgs {
     const double* A;            // the system whose rows [RP, RP + NP] hold Y and u^T
     const double* x_in; double* x_out; double* T;
     int compat; int token; int32_t* flag;
+    int riders_first;           // != 0: the x update in front of the tiles whatever the occupancy says (re-run after a timed-out Jnorm wait)
+    int inject;                 // fault injection (tests): riders placed behind the tiles never publish Jnorm
 };
 // C = sym(Pin) - Y Y^T on the lower-triangle tile pairs (K from sel[slot_nblk]*64);
 // K == 0: C = Pin exactly (ExtendKF.cpp:635-638 pass-through)

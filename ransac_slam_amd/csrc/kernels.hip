@@ -42,7 +42,13 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
                double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */)
 {
     __shared__ double sB[4][26];
-    if (sel_reset && blockIdx.x == 0 && threadIdx.x < SEL_COUNT) sel_reset[threadIdx.x] = 0;   // new frame
+    if (sel_reset && blockIdx.x == 0 && threadIdx.x < SEL_COUNT) {   // new frame: the frame scalars start from zero ...
+        // ... except that a status nobody has read yet (frames enqueued back to back without rslam_sync) is folded into a
+        // sticky slot first: an error of an unchecked frame is reported by the next sync instead of being erased here
+        const int old = sel_reset[threadIdx.x];
+        const int st = min(__shfl(old, SEL_STATUS, 16), __shfl(old, SEL_STATUS_FRONT, 16));
+        sel_reset[threadIdx.x] = ((int)threadIdx.x == SEL_STICKY) ? min(old, st) : 0;
+    }
     const int grp = (threadIdx.x & 63) >> 4;
     const int i = blockIdx.x * 4 + grp;
     const int sub = threadIdx.x & 15;
@@ -1439,7 +1445,7 @@ struct SweepFlags {
                                         // producer, no atomics: the tile workers poll the strips of their own row blocks
 };
 static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag block size");
-constexpr int SW_SPIN_LIMIT = 1 << 18;       // ~0.2 s; the longest legitimate wait is one diagonal block (~15 us)
+constexpr int SW_SPIN_LIMIT = 1 << 15;       // ~30 ms (a poll is ~1 us); the longest legitimate wait is one diagonal block (~15 us)
 
 // data that crosses workgroups inside the launch (see "Memory protocol" above)
 __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2625,7 +2631,9 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nu
 
 // RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
 // shared route too, bit 3 no register-only route for systems of <= 4 rows, bit 4 fault injection (the chain
-// workgroup does not run); set_sweep_exp_mask overrides the environment (tests)
+// workgroup does not run), bit 5 fault injection (the strips never announce their Y blocks: tile workers and the x update
+// run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep);
+// set_sweep_exp_mask overrides the environment (tests)
 static int g_sweep_exp_override = -1;
 void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }
 int sweep_exp_mask()
@@ -2657,7 +2665,7 @@ bool sweep_persistent_eligible(const SystemDims& d)
 bool sweep_fused_eligible(const SystemDims& d)
 {
     static const bool off = getenv("RSLAM_SWEEP_UNFUSED_K10") != nullptr;  // measurement: rank update as a launch of its own
-    if (off || !sweep_persistent_eligible(d)) return false;
+    if (off || (sweep_exp_mask() & 128) || !sweep_persistent_eligible(d)) return false;
     const int rp_blocks = d.RP / 64, nT = d.NP / 64;
     const int workers = device_cus() - 1 - d.ldA / 16 + 4 * (rp_blocks < 2 ? rp_blocks : 2) + 3;
     return (long)nT * (nT + 1) / 2 <= (long)WK_TILES * workers;
@@ -2810,8 +2818,10 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     // kernel and nothing of its output, so it does not deserve a launch of its own.  Group 0 also produces Jnorm,
     // which the bj == 0 tiles below wait for (they are dispatched after it and need it ~50 us later).
     if ((int)blockIdx.x >= rider0 && (int)blockIdx.x < rider0 + xu.groups) {
-        xupdate_rows((int)blockIdx.x - rider0, xu.d, sel, slot_nblk, slot_k, xu.A, xu.x_in, xu.x_out, xu.T, xu.compat, xu.flag, xu.token,
-                     reinterpret_cast<double (*)[17]>(lds));
+        // (xu.inject: fault injection for the tests -- riders dispatched behind the tiles never publish Jnorm, as if rider 0 had
+        //  not found a slot: the first block column must run into its bounded wait and the host must re-run with the riders first)
+        xupdate_rows((int)blockIdx.x - rider0, xu.d, sel, slot_nblk, slot_k, xu.A, xu.x_in, xu.x_out, xu.T, xu.compat,
+                     (xu.inject && rider0 != 0) ? nullptr : xu.flag, xu.token, reinterpret_cast<double (*)[17]>(lds));
         return;
     }
     const int tile_index = rider0 == 0 ? (int)blockIdx.x - xu.groups : (int)blockIdx.x;
@@ -2892,7 +2902,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         if (xu.groups > 0) {                        // Jnorm comes from group 0 of this launch
             int spins = 0;
             while (__hip_atomic_load(xu.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < xu.token) {
-                if (++spins > (1 << 22)) { atomicMin(xu.flag + (SEL_STATUS - SEL_XU_FLAG), -39); break; }   // (xu.flag = sel + SEL_XU_FLAG)
+                if (++spins > (1 << 16)) { atomicMin(xu.flag + (SEL_STATUS - SEL_XU_FLAG), -39); break; }   // (xu.flag = sel + SEL_XU_FLAG; ~50 ms)
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -3001,13 +3011,18 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
     // block column ask for it) -- unless every tile finds a slot at once (two workgroups per CU) and slots are left over:
     // then the riders go last, group 0 still starts at once, and no tile waits for a rider to vacate its slot (the late
     // tiles ended the launch ~2 us late at C3).
+    // (slots: what the device can hold of this kernel at once, from its real occupancy -- registers and dynamic LDS)
     static int slots = -1;
     if (slots < 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 0;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rank_update_kernel), 256,
+                                                         sizeof(double) * TG_LDS_DOUBLES) != hipSuccess) per_cu = 0;
+        slots = per_cu * device_cus();
     }
     static const bool riders_first = getenv("RSLAM_K10_RIDERS_FIRST") != nullptr;      // measurement
-    const int rider0 = (x.groups > 0 && tiles < slots && !riders_first) ? tiles : 0;
+    // behind the tiles only when tiles AND riders all find a slot at once (then rider 0 is resident whatever the dispatch order);
+    // x.riders_first: the host saw a timed-out Jnorm wait (somebody else holds compute units) and re-runs the safe order
+    const int rider0 = (x.groups > 0 && tiles + x.groups <= slots && !riders_first && !x.riders_first) ? tiles : 0;
     rank_update_kernel<<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
                                                                                              fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, rider0,
                                                                                              (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);

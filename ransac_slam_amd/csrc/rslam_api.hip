@@ -112,6 +112,11 @@ struct rslam_ctx {
     // CUs of this GPU) the update stage is re-run with the launch-per-step sweep, and so are the next frames for a while.
     int steps_frames_left = 0;
     int sweep_fallbacks = 0;
+    int consecutive_fallbacks = 0;
+    bool k10_riders_first = false;     // a Jnorm wait of the stand-alone rank update timed out once: riders in front from now on
+    int k10_reruns = 0;
+    int k10_inject = 0;                // fault injection (tests)
+    int rep_status = 0, rep_front = 0, rep_sticky = 0;   // status words of the frame in flight once read_status has taken them off the device
     bool sweep_can_overflow = false;   // the update stage in flight was enqueued with a shortened sweep ...
     bool frame_checked = true;         // ... and read_status has (not) looked at it yet
 };
@@ -131,6 +136,7 @@ static void mark_update_enqueued(rslam_ctx* c, const int32_t* d_sup)
     // the persistent sweep is one launch sized for the largest inlier count: nothing to overflow
     c->sweep_can_overflow = !sweep_is_persistent(c) && (c->cap_li < rp_blocks || c->cap_hi < rp_blocks);
     c->frame_checked = false;
+    c->rep_status = c->rep_front = c->rep_sticky = 0;
     c->have_post = true;
 }
 
@@ -144,6 +150,32 @@ static void invalidate_graph(rslam_ctx* c)
 }
 
 extern "C" int rslam_destroy(rslam_ctx* c);
+
+// Largest squared undistorted radius at which the scoring kernel's six Newton steps (camera_model.h distort_fm_score) are at
+// the fixed point of ExtendKF::distort_fm's iteration: found by running the iteration on a geometric grid of radii (host
+// arithmetic; the device's slope reciprocals differ by 2^-26, which moves the contraction by that much, not the fixed point),
+// with a 10 % safety factor on the radius.  Pairs beyond it take the reference's ten-step sequence.
+static double score_fast_radius2(double k1, double k2, double dx, double dy, int nRows, int nCols)
+{
+    auto step = [&](double rd, double ru) {
+        const double v2 = rd * rd, v4 = v2 * v2;
+        const double f = rd + k1 * (v2 * rd) + k2 * (v4 * rd) - ru, fp = 1 + 3 * k1 * v2 + 5 * k2 * v4;
+        return rd - f / fp;
+    };
+    const double diag = sqrt((double)nCols * dx * (double)nCols * dx + (double)nRows * dy * (double)nRows * dy);
+    double good = 0.0;
+    for (double ru = 1e-3 * diag; ru < 64.0 * diag; ru *= 1.02) {
+        const double ru2 = ru * ru;
+        double rd = ru / (1 + k1 * ru2 + k2 * ru2 * ru2);
+        for (int k = 0; k < 6; ++k) rd = step(rd, ru);
+        double ref = rd;
+        for (int k = 0; k < 60; ++k) ref = step(ref, ru);
+        if (!(fabs(rd - ref) <= 1e-14 * fabs(ref)) || !(ref > 0.0)) break;      // (also a model whose iteration goes astray)
+        good = ru;
+    }
+    good *= 0.9;
+    return good * good;
+}
 
 extern "C" const char* rslam_version(void) { return "rslam-hip 0.2 (gfx950)"; }
 
@@ -177,6 +209,7 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->cam.f = cfg->cam.f; c->cam.dx = cfg->cam.dx; c->cam.dy = cfg->cam.dy;
     c->cam.inv_dx = 1.0 / cfg->cam.dx; c->cam.inv_dy = 1.0 / cfg->cam.dy; c->cam.f_ku = cfg->cam.f * (1.0 / cfg->cam.dx);
     c->cam.nRows = cfg->cam.nRows; c->cam.nCols = cfg->cam.nCols;
+    c->cam.ru2_fast = score_fast_radius2(cfg->cam.k1, cfg->cam.k2, cfg->cam.dx, cfg->cam.dy, cfg->cam.nRows, cfg->cam.nCols);
     c->device = device;
     // every failure path below goes through rslam_destroy, which releases whatever exists so far
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->own_stream = nullptr; (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
@@ -513,6 +546,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         xu.d = d; xu.A = Ysys; xu.x_in = x_in; xu.x_out = x_out; xu.T = c->d_T.p; xu.compat = c->cfg.compat;
         xu.token = (slot_k == SEL_K_LI) ? 1 : 2;              // sel[] is zeroed at the start of a frame (predict_kernel)
         xu.flag = sel + SEL_XU_FLAG;
+        xu.riders_first = c->k10_riders_first ? 1 : 0; xu.inject = c->k10_inject;
         launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
                            order, c->RP > 0 ? c->d_T.p : nullptr, slot_k, &xu);
     }
@@ -580,6 +614,35 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     int rc = read_status_raw(c, sel);
     if (rc) return rc;
     const int rp_blocks = c->RP / 64;
+    // statuses of frames that were enqueued behind each other without a sync in between (predict_kernel folds the word it
+    // resets into SEL_STICKY): reported with this frame, then cleared
+    int sticky = sel[SEL_STICKY];
+    if (sticky != 0) HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STICKY, 0, sizeof(int32_t), c->stream));
+    if (c->frame_checked) {
+        // this frame has been reported before: its status words were taken off the device then (so that the next frame's
+        // reset does not report them a second time) and are remembered here
+        if (c->rep_status < sel[SEL_STATUS]) sel[SEL_STATUS] = c->rep_status;
+        if (c->rep_front < sel[SEL_STATUS_FRONT]) sel[SEL_STATUS_FRONT] = c->rep_front;
+        if (c->rep_sticky < sticky) sticky = c->rep_sticky;
+    }
+    if (sel[SEL_STATUS] == -39 && c->last_sup && c->predicted && c->have_meas && !c->k10_riders_first) {
+        // The first block column of the stand-alone rank update waited for Jnorm in vain: the riders that produce it had been
+        // placed behind the tiles and did not become resident (somebody else holds compute units).  Re-run the update stage
+        // with the riders in front -- dispatched first, they cannot be locked out by the tiles -- and keep that order.
+        c->last_raw_status = sel[SEL_STATUS];
+        c->k10_riders_first = true;
+        ++c->k10_reruns;
+        invalidate_graph(c);
+        const int timing = c->timing; c->timing = 0;
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_CAP_FLAG, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
+        rc = enqueue_update(c, c->last_sup);
+        c->timing = timing;
+        if (rc) return rc;
+        rc = read_status_raw(c, sel);
+        if (rc) return rc;
+    }
     if (sel[SEL_CAP_FLAG] != 0 && c->last_sup) {
         c->cap_li = c->cap_hi = 1 << 20;
         invalidate_graph(c);
@@ -596,12 +659,22 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         rc = read_status_raw(c, sel);
         if (rc) return rc;
     }
-    if (sel[SEL_STATUS] <= -30 && c->last_sup && sweep_is_persistent(c)) {
+    // (codes -31..-38 and the chain's per-block -36-10k: waits of the persistent sweep and its tile workers; -39 is the
+    //  rider hand-over of the stand-alone rank update, handled below)
+    const bool sweep_timeout = sel[SEL_STATUS] <= -30 && sel[SEL_STATUS] != -39;
+    if (sweep_timeout && c->last_sup && sweep_is_persistent(c)) {
+        if (!c->predicted || !c->have_meas) {     // the frame's inputs are gone (a new prior was installed unchecked): nothing to re-run from
+            c->last_raw_status = sel[SEL_STATUS];
+            c->frame_checked = true;
+            return RSLAM_ERR_HIP;
+        }
         // A bounded wait of the persistent sweep ran out: its workgroups were not all resident (another user of the GPU), not
         // an error of the data.  Re-run the update stage with the launch-per-step sweep at full length, and keep to it for
         // the next frames.
         c->last_raw_status = sel[SEL_STATUS];
-        c->steps_frames_left = 64;
+        // back off exponentially: 64, 128, ... 4096 frames on the launch-per-step sweep while the timeouts keep coming
+        c->steps_frames_left = 64 << (c->consecutive_fallbacks < 6 ? c->consecutive_fallbacks : 6);
+        ++c->consecutive_fallbacks;
         ++c->sweep_fallbacks;
         c->cap_li = c->cap_hi = 1 << 20;
         invalidate_graph(c);
@@ -617,8 +690,16 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         if (rc) return rc;
     } else if (c->steps_frames_left > 0 && c->last_sup && !c->frame_checked) {
         if (--c->steps_frames_left == 0) invalidate_graph(c);     // back to the persistent sweep: new launch sequence
+    } else if (c->steps_frames_left == 0 && c->last_sup && !c->frame_checked && sel[SEL_STATUS] > -30) {
+        c->consecutive_fallbacks = 0;                             // a persistent sweep went through
     }
+    if (sel[SEL_STATUS] != 0 || sel[SEL_STATUS_FRONT] != 0) {
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS_FRONT, 0, sizeof(int32_t), c->stream));
+    }
+    c->rep_status = sel[SEL_STATUS]; c->rep_front = sel[SEL_STATUS_FRONT]; c->rep_sticky = sticky;
     if (sel[SEL_STATUS_FRONT] < sel[SEL_STATUS]) sel[SEL_STATUS] = sel[SEL_STATUS_FRONT];
+    if (sticky < sel[SEL_STATUS]) sel[SEL_STATUS] = sticky;
     if (sel[SEL_STATUS] <= -30) {                 // (still: which wait it was is kept for diagnosis)
         c->last_raw_status = sel[SEL_STATUS];
         sel[SEL_STATUS] = RSLAM_ERR_HIP;
@@ -882,7 +963,11 @@ static int settle_posterior(rslam_ctx* c)
 {
     if (!c->have_post) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
-    if (c->have_meas && c->last_sup && c->sweep_can_overflow && !c->frame_checked) {
+    // An update stage that nobody has looked at yet is checked before its posterior is used: a shortened launch-per-step
+    // sweep may have to be re-run, and a bounded wait of the persistent sweep may have run out (another user of the GPU),
+    // in which case the posterior in the buffers is not the frame's -- read_status re-runs the stage while the frame's
+    // inputs are still in place (the next predict_kernel would also erase the status word).
+    if (c->have_meas && c->last_sup && !c->frame_checked) {
         const int st = read_status(c, nullptr);
         if (st < 0) return st;
     }
@@ -1117,7 +1202,7 @@ extern "C" int rslam_get_counters(rslam_ctx* c, int32_t* graph_captures, int32_t
 {
     if (!c) return RSLAM_ERR_ARG;
     if (graph_captures) *graph_captures = c->graph_captures;
-    if (sweep_reruns) *sweep_reruns = c->reruns + c->sweep_fallbacks;
+    if (sweep_reruns) *sweep_reruns = c->reruns + c->sweep_fallbacks + c->k10_reruns;
     return RSLAM_OK;
 }
 
@@ -1436,6 +1521,8 @@ namespace rslam { int debug_sweep_stamps(unsigned long long* out, int enable); }
 extern "C" int rslam_debug_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
 // diagnostics / fault injection (not part of include/rslam.h): RSLAM_SWEEP_EXP switches from the host, -1 = environment
 extern "C" int rslam_debug_set_sweep_exp(int mask) { rslam::set_sweep_exp_mask(mask); return RSLAM_OK; }
+// fault injection (tests), per context: riders of the stand-alone rank update that sit behind the tiles never publish Jnorm
+extern "C" int rslam_debug_set_k10_inject(rslam_ctx* c, int on) { if (!c) return RSLAM_ERR_ARG; c->k10_inject = on ? 1 : 0; invalidate_graph(c); return RSLAM_OK; }
 
 extern "C" int rslam_debug_sweep_stamps(rslam_ctx* c, unsigned long long* out, int enable)
 {

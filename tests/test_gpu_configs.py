@@ -23,7 +23,10 @@ def close_x(a, b):
 
 
 def close_P(a, b):
-    return np.max(np.abs(a - b)) <= P_TOL * float(np.max(np.abs(b)))
+    """norm-wise and scale-aware: |dP_ij| <= P_TOL * sqrt(P_ii P_jj) (see tests/test_gpu_parity.py)"""
+    d = np.sqrt(np.abs(np.diag(b)))
+    return (np.max(np.abs(a - b)) <= P_TOL * float(np.max(np.abs(b)))
+            and bool(np.all(np.abs(a - b) <= P_TOL * np.outer(d, d) + 1e-300)))
 
 
 @pytest.fixture(scope="module")

@@ -1,0 +1,196 @@
+"""The x / covariance update inside the persistent factor sweep (tile workers, kernels.hip), its bounded waits, and
+the host's handling of frames nobody has looked at yet.  Replaces ExtendKF::update's tail (ExtendKF.cpp:606-634)
+on a different schedule, so every route is held against the oracle and against the stand-alone rank update.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ransac_slam_amd import default_config
+from ransac_slam_amd.synth import make_frame, remeasure
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (the product path has no CPU fallback)")
+    from ransac_slam_amd import api
+    L = api.lib()
+    L.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
+    L.rslam_debug_last_raw_status.argtypes = [C.c_void_p]
+    L.rslam_debug_set_k10_inject.argtypes = [C.c_void_p, C.c_int]
+    return api
+
+
+def close_x(a, b, tol=1e-9):
+    return np.max(np.abs(a - b)) <= tol * max(1.0, float(np.max(np.abs(b))))
+
+
+def close_P(a, b, tol=1e-9):
+    """norm-wise and scale-aware: |dP_ij| <= tol * sqrt(P_ii P_jj) (the diagonal of p_k_k spans 1e-6 .. 0.25 rho^2)"""
+    d = np.sqrt(np.abs(np.diag(b)))
+    return (np.max(np.abs(a - b)) <= tol * float(np.max(np.abs(b)))
+            and np.all(np.abs(a - b) <= tol * np.outer(d, d) + 1e-300))
+
+
+def oracle_frame(oracle_lib, fr, cfg, z=None, draws=None):
+    o = oracle_lib.Oracle(cfg, structure=1)
+    _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z if z is None else z, ic, fr.draws if draws is None else draws)
+    assert min(o.margins()) > 1e-9
+    return ic, r0
+
+
+@pytest.mark.parametrize("compat,L,H,seed", [(1, 90, 120, 21), (0, 24, 60, 12), (0, 40, 80, 13), (0, 90, 120, 13), (1, 300, 200, 2),
+                                             (0, 300, 200, 2)])
+def test_fused_update_equals_standalone_rank_update(hip, oracle_lib, compat, L, H, seed):
+    """Same frame with the update inside the sweep launch (default) and with the rank update as a launch of its own
+    (RSLAM_SWEEP_EXP bit 7): both against the oracle, and against each other to rounding.  The frames cover the
+    register-only route (r <= 4), the in-LDS single-block route, and systems of several diagonal blocks."""
+    fr = make_frame(L=L, H=H, seed=seed)
+    cfg = default_config(compat=compat, adaptive=0)
+    ic, r0 = oracle_frame(oracle_lib, fr, cfg)
+    out = {}
+    for mask in (0, 128):
+        hip.lib().rslam_debug_set_sweep_exp(mask)
+        try:
+            g = hip.RslamHip(cfg)
+            g.predict(fr.types, fr.x_pred, fr.P_pred)
+            out[mask] = g.ransac_update(fr.z, ic, fr.draws)
+            g.close()
+        finally:
+            hip.lib().rslam_debug_set_sweep_exp(-1)
+        r1 = out[mask]
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"]), mask
+        Dsym = r1["P_new"] - r1["P_new"].T          # exactly symmetric, except the 4 x 4 block (J P44) J^T, symmetric to
+        assert np.abs(Dsym[3:7, 3:7]).max() <= 1e-15 * np.abs(r1["P_new"][3:7, 3:7]).max()     # rounding as in the reference
+        Dsym[3:7, 3:7] = 0                                                                   # (ExtendKF.cpp:632)
+        assert not Dsym.any()
+        assert abs(np.linalg.norm(r1["x_new"][3:7]) - 1.0) < 1e-14
+    assert close_x(out[0]["x_new"], out[128]["x_new"], 1e-12) and close_P(out[0]["P_new"], out[128]["P_new"], 1e-11)
+
+
+def test_alternating_frames_on_one_context(hip, oracle_lib):
+    """The tile workers read Y while the strips of the same launch are still writing later blocks of it, through
+    write-through stores and sc1 transfers.  A stale line would carry the PREVIOUS frame's Y: two different
+    measurement sets alternate on one context (same buffers, hipGraph replay), each posterior against the oracle."""
+    fr = make_frame(L=300, H=200, seed=2)
+    cfg = default_config(compat=0, adaptive=0)
+    sets = [(fr.z, fr.draws)] + [remeasure(fr, 500 + k, frac_outlier=0.1 + 0.3 * k, H=200)[::2] for k in range(2)]
+    g = hip.RslamHip(cfg)
+    ic, _ = oracle_frame(oracle_lib, fr, cfg)
+    ref = [oracle_frame(oracle_lib, fr, cfg, z=z, draws=d)[1] for (z, d) in sets]
+    assert not np.allclose(ref[0]["P_new"], ref[1]["P_new"], rtol=1e-6, atol=0)
+    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+    for rep in range(3):
+        for k, (z, d) in enumerate(sets):
+            g.load_measurements(z, ic, d)
+            g.step_frame(True)
+            g.step_frame(True)                       # back to back: the second replay starts while nothing was synchronised
+            g.sync()
+            r1 = g.fetch_results()
+            assert np.array_equal(r1["li"], ref[k]["li"]) and np.array_equal(r1["hi"], ref[k]["hi"]), (rep, k)
+            assert close_x(r1["x_new"], ref[k]["x_new"]) and close_P(r1["P_new"], ref[k]["P_new"]), (rep, k)
+    assert g.counters()["sweep_reruns"] == 0
+    g.close()
+
+
+def test_tile_workers_timeout_falls_back(hip, oracle_lib):
+    """Fault injection (RSLAM_SWEEP_EXP bit 5): the strips never announce their Y blocks.  Every tile worker and every
+    x-update strip must leave through its bounded wait WITHOUT writing the posterior, the host must notice, re-run the
+    update stage on the launch-per-step sweep + stand-alone rank update, and return the right answer."""
+    fr = make_frame(L=90, H=120, seed=321)
+    cfg = default_config(compat=0, adaptive=1)
+    ic, r0 = oracle_frame(oracle_lib, fr, cfg)
+    hip.lib().rslam_debug_set_sweep_exp(32)
+    try:
+        g = hip.RslamHip(cfg)
+        g.predict(fr.types, fr.x_pred, fr.P_pred)
+        r1 = g.ransac_update(fr.z, ic, fr.draws)
+    finally:
+        hip.lib().rslam_debug_set_sweep_exp(-1)
+    assert hip.lib().rslam_debug_last_raw_status(g._h) in (-37, -38)
+    assert g.counters()["sweep_reruns"] >= 1
+    assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+    assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+    g.close()
+
+
+def test_unchecked_timeout_is_settled_before_ekf_prediction(hip, oracle_lib):
+    """A persistent sweep that timed out in a frame nobody synchronised on (rslam_step_frame, no rslam_sync) must be
+    noticed and re-run when rslam_ekf_prediction turns its posterior into the next prior -- while the frame's inputs are
+    still in place -- and rslam_load_measurements for the next frame must then simply work."""
+    fr = make_frame(L=90, H=120, seed=322)
+    cfg = default_config(compat=0, adaptive=1)
+    ic, r0 = oracle_frame(oracle_lib, fr, cfg)
+    xp0, Pp0 = oracle_lib.ekf_prediction(r0["x_new"], r0["P_new"], 1.0, 0.007, 0.007)
+    hip.lib().rslam_debug_set_sweep_exp(16)              # the chain workgroup never shows up
+    try:
+        g = hip.RslamHip(cfg)
+        g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+        g.step_frame(True)                               # enqueued, not looked at
+        g.ekf_prediction(1.0, 0.007, 0.007)              # must settle the frame first (re-run inside)
+    finally:
+        hip.lib().rslam_debug_set_sweep_exp(-1)
+    assert hip.lib().rslam_debug_last_raw_status(g._h) <= -30 and g.counters()["sweep_reruns"] >= 1
+    xp1, Pp1 = g.fetch_prior()
+    assert close_x(xp1, xp0) and close_P(Pp1, Pp0)
+    z2, _, d2 = remeasure(fr, 77, frac_outlier=0.2, H=120)
+    g.predict_resident()
+    g.load_measurements(z2, ic, d2)                      # no stale status, no state error
+    g.step_frame(True); g.sync()
+    g.close()
+
+
+def test_rank_update_rider_timeout_reruns_with_riders_first(hip, oracle_lib):
+    """The stand-alone rank update (systems the sweep cannot host: here forced by RSLAM_SWEEP_EXP bit 7) places the x-update
+    riders behind the tiles when everything is resident at once.  Fault injection: such riders never publish Jnorm -- the
+    first block column runs into its bounded wait (-39), the host re-runs the update stage with the riders in front and
+    keeps that order."""
+    fr = make_frame(L=90, H=120, seed=323)
+    cfg = default_config(compat=0, adaptive=1)
+    ic, r0 = oracle_frame(oracle_lib, fr, cfg)
+    hip.lib().rslam_debug_set_sweep_exp(128)
+    try:
+        g = hip.RslamHip(cfg)
+        hip.lib().rslam_debug_set_k10_inject(g._h, 1)
+        g.predict(fr.types, fr.x_pred, fr.P_pred)
+        r1 = g.ransac_update(fr.z, ic, fr.draws)
+        assert hip.lib().rslam_debug_last_raw_status(g._h) == -39 and g.counters()["sweep_reruns"] >= 1
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+        n_before = g.counters()["sweep_reruns"]
+        g.predict(fr.types, fr.x_pred, fr.P_pred)       # riders first from now on: the injection no longer applies
+        r2 = g.ransac_update(fr.z, ic, fr.draws)
+        assert g.counters()["sweep_reruns"] == n_before and close_P(r2["P_new"], r0["P_new"])
+        g.close()
+    finally:
+        hip.lib().rslam_debug_set_sweep_exp(-1)
+
+
+def test_status_of_an_unsynced_frame_is_not_lost(hip):
+    """Frames enqueued back to back without rslam_sync: the next frame's reset used to erase the status word of the one
+    before.  A frame that fails (covariance not positive definite) followed by a good one: the failure is reported by
+    the next sync -- once."""
+    fr = make_frame(L=20, H=16, seed=403)
+    cfg = default_config(compat=0)
+    g = hip.RslamHip(cfg)
+    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    g.step_predict(); g.sync()
+    ic = (fr.ic & g.fetch_prediction()[1]).astype(np.uint8)
+    g.load_frame(fr.types, fr.x_pred, -10.0 * np.eye(fr.n), fr.z, ic, fr.draws)
+    g.step_frame(False)                                   # fails on the device; nobody looks
+    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)     # (uploads wait for the stream, they read no status)
+    g.step_frame(False)
+    with pytest.raises(hip.RslamError) as e:
+        g.sync()
+    assert e.value.code == -6
+    g.step_frame(False)
+    g.sync()                                              # reported once: the context is clean again
+    g.close()
