@@ -37,7 +37,7 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bench_c3_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_bench_c3_pmc_summary.csv")
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -47,12 +47,27 @@ def pmc_traffic_bytes(kernel_substr):
     gfx950 (MI355X_MICROARCH.md, HBM section; confirmed on pht_kernel).  'max' = the large (HI) pass."""
     import csv
     try:
+        # (a summary older than the kernels it describes would be a stale figure: not reported then)
+        src = [os.path.join(ROOT, "ransac_slam_amd", "csrc", f) for f in ("kernels.hip", "tile_gemm.h")]
+        if os.path.getmtime(PMC_SUMMARY) < max(os.path.getmtime(f) for f in src) - 1.0:
+            return None
         rows = [r for r in csv.DictReader(open(PMC_SUMMARY)) if kernel_substr in r["kernel"]]
         fetch = max(float(r["max"]) for r in rows if r["counter"] == "FETCH_SIZE")
         write = max(float(r["max"]) for r in rows if r["counter"] == "WRITE_SIZE")
         return (2.0 * fetch + write) * 1024.0
     except Exception:
         return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def cpu_baseline(frame, cfg, sample_iters, seed):
@@ -112,7 +127,7 @@ def cpu_baseline(frame, cfg, sample_iters, seed):
                         f"(scaled x{H / max(iters_done, 1):.0f}) + both updates {t3 - t2:.2f}s; "
                         f"estimated {est_frame_s:.1f} s/frame; note the RANSAC update flags of the sample differ "
                         f"from the full run only in fixed mode"),
-                est_ms_per_frame=est_frame_s * 1e3, host_cpus=os.cpu_count())
+                est_ms_per_frame=est_frame_s * 1e3, host_cpus=os.cpu_count(), cpu_model=cpu_model())
 
 
 def visible_ic(ctx, frame):
@@ -199,6 +214,26 @@ class Runner:
     def result(self):
         res = self.ctx.fetch_results(want_P=False)
         return {k: int(res[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")}
+
+
+def eager_stage_times(ctx, nrep, warm=5):
+    """Per-stage hipEvent times of `nrep` eager frames: (mean per stage, outliers).  A frame whose total exceeds 3x the
+    median is kept whole -- its stage times and the raw status -- so that a slow frame names the stage it was slow in
+    (passive: no extra runs)."""
+    ctx.enable_timing(True)
+    for _ in range(warm):
+        ctx.step_frame(False); ctx.sync()
+    frames = []
+    for _ in range(nrep):
+        ctx.step_frame(False); ctx.sync()
+        frames.append(ctx.timings())
+    ctx.enable_timing(False)
+    tot = np.array([f["total_us"] for f in frames])
+    med = float(np.median(tot))
+    keep = [f for f in frames if f["total_us"] <= 3.0 * med] or frames
+    mean = {k: float(np.mean([f[k] for f in keep])) for k in frames[0]}
+    outliers = [{"frame": i, **{k: round(v, 1) for k, v in f.items()}} for i, f in enumerate(frames) if f["total_us"] > 3.0 * med]
+    return mean, outliers, med
 
 
 def sequence_run(runner, n_frames=32):
@@ -305,6 +340,39 @@ def main():
             "timed_region_repeats_ms_per_step": [e / args.steps * 1e3 for e in run.elapsed_runs],
             "result": {k: int(res[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")},
         }
+    # ---- N > 1: where a sharded frame goes on every rank (so that a scaling line can be read): device time of the rank's own
+    # phase 0 (predict + P H^T + scoring of its hypothesis slice), of the all-gather of the supports, and of phase 1
+    # (consensus + both updates, replicated), from events on the stream that carries all three
+    if world > 1:
+        eng = run.sharded.engine
+        sf = run.sharded
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(20)]
+        with eng.stream_context():
+            for e4 in evs:
+                e4[0].record()
+                eng.step_phase(0, sf.begin, sf.end, sf.local)
+                e4[1].record()
+                dist.all_gather_into_tensor(sf.all, sf.local)
+                e4[2].record()
+                eng.step_phase(1, sf.begin, sf.end, sf.all)
+                e4[3].record()
+        run.fence()
+        mine = torch.tensor([float(np.median([e4[i].elapsed_time(e4[i + 1]) * 1e3 for e4 in evs[5:]])) for i in range(3)],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        if rank == 0:
+            tab = np.array([t.cpu().numpy() for t in allr])
+            out["multi_gpu"] = {"per_rank_phase0_predict_score_us": [round(float(v), 2) for v in tab[:, 0]],
+                                "per_rank_allgather_us": [round(float(v), 2) for v in tab[:, 1]],
+                                "per_rank_phase1_consensus_updates_us": [round(float(v), 2) for v in tab[:, 2]],
+                                "supports_bytes_gathered": int(4 * sf.chunk * world),
+                                "note": "medians of 15 frames, torch events on the stream that carries kernels and collective; "
+                                        "only phase 0 shards (hypothesis slices), phase 1 is replicated: frame time cannot drop "
+                                        "with N, hypotheses x features / s grows until the all-gather latency shows",
+                                "scale_line": "value = C3 weak-scaled (1000 hypotheses per GPU); BASELINE's C4 (4000 hypotheses "
+                                              "in total, strong: 500 per GPU at N = 8) is under the key c4 -- quote c4.value for "
+                                              "the strong-scaling curve and value for the weak one"}
     # ---- spread of the per-step times (every rank takes part in the fences)
     if not args.no_extras:
         ts = run.per_step_ms(min(args.steps, 200))
@@ -334,63 +402,111 @@ def main():
                          "unit": "hypotheses*features/s", "scaling": "strong", "result": c4.result(),
                          "config": config_of(c4, WORKLOADS["C4"])}
         c4.ctx.close()
+        if args.compat == 1:                                   # (compat = 1 makes the RANSAC stage degenerate: the corrected mode too)
+            c4b = Runner(args, WORKLOADS["C4"], world, rank, local_rank, 0, use_graph)
+            e4b = c4b.timed(args.steps, args.warmup)
+            if rank == 0:
+                out["c4"]["compat0"] = {"ms_per_step": e4b / args.steps * 1e3, "value": c4b.H_total * c4b.m * args.steps / e4b,
+                                        "result": c4b.result(), "config": config_of(c4b, WORKLOADS["C4"])}
+            c4b.ctx.close()
 
     # ---- BASELINE config C5 (1000 landmarks, n = 6013): the MFMA-utilisation stress configuration, single GPU only
     if not args.no_extras and args.workload != "C5" and world == 1 and rank == 0:
-        c5 = Runner(args, WORKLOADS["C5"], world, rank, local_rank, args.compat, use_graph)
-        k5 = max(5, min(args.steps, 20))
-        e5 = c5.timed(k5, 2, repeats=1)
-        r5 = c5.result()
-        c5.ctx.enable_timing(True)
-        acc5 = {}
-        for _ in range(3):
-            c5.ctx.step_frame(False); c5.ctx.sync()
-        for _ in range(5):
-            c5.ctx.step_frame(False); c5.ctx.sync()
-            for kk, vv in c5.ctx.timings().items():
-                acc5[kk] = acc5.get(kk, 0.0) + vv / 5
-        n5 = int(c5.frame.n)
-        us5, rr5 = max((acc5["rank_update_hi_us"], 2 * r5["n_hi"]), (acc5["rank_update_li_us"], 2 * r5["n_li"]))
-        f5 = float(n5) * (n5 + 1) * rr5
-        out["c5"] = {"ms_per_step": e5 / k5 * 1e3, "steps": k5, "result": r5, "config": config_of(c5, WORKLOADS["C5"]),
-                     "stage_us": {kk: round(vv, 1) for kk, vv in acc5.items()},
+        out["c5"] = {}
+        for cm in sorted({args.compat, 0}, reverse=True):
+            c5 = Runner(args, WORKLOADS["C5"], world, rank, local_rank, cm, use_graph)
+            k5 = max(5, min(args.steps, 20))
+            e5 = c5.timed(k5, 2, repeats=1)
+            r5 = c5.result()
+            acc5, out5, _ = eager_stage_times(c5.ctx, 5, warm=3)
+            n5 = int(c5.frame.n)
+            us5, rr5 = max((acc5["rank_update_hi_us"], 2 * r5["n_hi"]), (acc5["rank_update_li_us"], 2 * r5["n_li"]))
+            f5 = float(n5) * (n5 + 1) * rr5
+            line5 = {"ms_per_step": e5 / k5 * 1e3, "steps": k5, "result": r5, "config": config_of(c5, WORKLOADS["C5"]),
+                     "stage_us": {kk: round(vv, 1) for kk, vv in acc5.items()}, "outliers": out5,
                      "rank_update": {"launch_us": us5, "rank_r": rr5, "achieved_TFLOPs": f5 / (us5 * 1e-6) * 1e-12 if us5 > 0 else 0.0,
                                      "frac_of_fp64_mfma_peak": f5 / (us5 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if us5 > 0 else 0.0},
-                     "note": "too large for the persistent sweep (508 strips > CUs): launch-per-step sweep, sized from the previous frame"}
-        c5.ctx.close()
+                     "update_mode": c5.ctx.debug_update_mode(),
+                     "note": "too large for the persistent sweep (508 strips > CUs): launch-per-step sweep + stand-alone rank update"}
+            if cm == args.compat:
+                out["c5"].update(line5)
+            else:
+                out["c5"]["compat0"] = line5
+            c5.ctx.close()
 
     # ---- per-kernel durations (HIP events on the launch stream, eager frames) ----
     # (at N > 1 too: rank 0 times eager single-GPU frames of its own -- no collective inside -- while the others wait at the
     #  final barrier; the inlier counts of THOSE frames price the kernel)
     if rank == 0:
-        ctx.enable_timing(True)
-        acc, nrep = {}, 30
-        for _ in range(5):
-            ctx.step_frame(False); ctx.sync()
-        for _ in range(nrep):
-            ctx.step_frame(False)
-            ctx.sync()
-            for k, v in ctx.timings().items():
-                acc[k] = acc.get(k, 0.0) + v / nrep
-        ctx.enable_timing(False)
+        nrep = 30
+        acc, outl, med_total = eager_stage_times(ctx, nrep)
         out["stage_us"] = {k: round(v, 2) for k, v in acc.items()}
+        out["outliers"] = {"frames_over_3x_median": outl, "median_total_us": round(med_total, 1), "frames": nrep,
+                           "note": "eager frames whose total device time exceeded 3x the median, with the stage times of that very frame"}
         n = int(frame.n)
         res_e = ctx.fetch_results(want_P=False)
         k_li, k_hi = res_e["n_li"], res_e["n_hi"]
-        passes = [("K10 rank_update_kernel (HI pass)", acc["rank_update_hi_us"], 2 * k_hi),
-                  ("K10 rank_update_kernel (LI pass)", acc["rank_update_li_us"], 2 * k_li)]
-        name, us, r = max(passes, key=lambda p: p[1])
-        flops = float(n) * (n + 1) * r            # lower-triangle tiles only: n(n+1)r (SURVEY 8d F_rank)
-        achieved = flops / (us * 1e-6) * 1e-12 if us > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                           "traffic": pmc_traffic_bytes("rank_update_kernel") if args.workload == "C3" else None,
-                           "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes committed under profiles/ "
-                                           "(not collectable inside this process); algorithmic bytes: read P + Y, write P",
-                           "algorithmic_bytes_per_launch": 8.0 * (2.0 * n * n + n * r),
-                           "algorithmic_flops_per_launch": flops, "launch_us": us, "rank_r": r,
-                           "note": "n(n+1)r flops of P - Y Y^T on lower-triangle tile pairs; launch duration from "
-                                   "hipEvents bracketing the kernel on its stream, mean of %d eager frames" % nrep}
+        mode = ctx.debug_update_mode()
+        out["update_mode"] = {0: "launch-per-step sweep + stand-alone rank update", 1: "persistent sweep + stand-alone rank update",
+                              2: "persistent sweep with the x / covariance update inside its launch"}[mode]
+        r = 2 * k_hi
+        f_rank = float(n) * (n + 1) * r              # lower-triangle tiles only: n(n+1)r (SURVEY 8d F_rank)
+        f_sweep = r ** 3 / 3.0 + float(n) * r * r    # SURVEY 8d F_update terms of the factor sweep
+        # K10 on its own, same shape, same run: hipEvents on the context's stream around back-to-back launches
+        us_k10 = ctx.k_rank_update_time(n, max(r, 32), 20) if r > 0 else 0.0
+        k10 = {"kernel": "rank_update_kernel (stand-alone, n = %d, r = %d)" % (n, r), "launch_us": us_k10,
+               "algorithmic_flops_per_launch": f_rank,
+               "achieved_TFLOPs": f_rank / (us_k10 * 1e-6) * 1e-12 if us_k10 > 0 else 0.0,
+               "frac_of_fp64_mfma_peak": f_rank / (us_k10 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if us_k10 > 0 else 0.0,
+               "traffic": pmc_traffic_bytes("rank_update_kernel") if args.workload == "C3" else None,
+               "algorithmic_bytes_per_launch": 8.0 * (2.0 * n * n + n * r),
+               "note": "the MFMA kernel of the path timed alone (rslam_k_rank_update_time: 20 back-to-back launches between "
+                       "hipEvents on its stream)"}
+        if mode == 2:
+            # the dominant launch of a frame: factor sweep + rank update + x update of the HI pass in ONE kernel
+            # (stage events EV_HI_FACTOR0/1 bracket exactly that launch on its stream)
+            us = acc["factor_hi_us"]
+            flops = f_sweep + f_rank
+            achieved = flops / (us * 1e-6) * 1e-12 if us > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "sweep_persistent_kernel (HI pass: factor sweep + K9/K10/K11 inside the launch)",
+                               "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                               "traffic": pmc_traffic_bytes("sweep_persistent_kernel") if args.workload == "C3" else None,
+                               "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes committed under profiles/ (2 x FETCH_SIZE + "
+                                               "WRITE_SIZE KiB; null when the summary is older than the kernels)",
+                               "algorithmic_bytes_per_launch": 8.0 * (2.0 * n * n + 2.0 * n * r),
+                               "algorithmic_flops_per_launch": flops, "launch_us": us, "rank_r": r,
+                               "flops_rank_update": f_rank, "flops_factor_sweep": f_sweep,
+                               "rank_update_standalone": k10,
+                               "note": "n(n+1)r flops of P - Y Y^T (lower-triangle tile pairs) + r^3/3 + n r^2 of the blocked Cholesky "
+                                       "sweep, over the duration of the one launch that now does both (hipEvents bracketing it on its "
+                                       "stream, mean of %d eager frames).  The launch is paced by the serial pivot chain of ONE workgroup "
+                                       "(r dependent pivots); the rank update runs under it on the compute units the sweep leaves idle" % nrep}
+            try:
+                st = ctx.debug_sweep_stamps()
+                ends = st[0, :, 5][st[0, :, 5] > 0]
+                if len(ends) and st[5, 0, 4] > 0:
+                    out["roofline"]["exposed_tail_us"] = float(st[5, 0, 4] - ends.max()) / 100.0
+                    out["roofline"]["chain_us"] = float(ends.max() - st[0, 0, 0]) / 100.0
+                    out["roofline"]["tail_note"] = ("one stamped frame: time from the end of the pivot chain to the last store of tile "
+                                                    "worker 0 = what is left of the rank update behind the sweep")
+            except Exception:
+                pass
+        else:
+            passes = [("K10 rank_update_kernel (HI pass)", acc["rank_update_hi_us"], 2 * k_hi),
+                      ("K10 rank_update_kernel (LI pass)", acc["rank_update_li_us"], 2 * k_li)]
+            name, us, r = max(passes, key=lambda p: p[1])
+            flops = float(n) * (n + 1) * r
+            achieved = flops / (us * 1e-6) * 1e-12 if us > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                               "traffic": pmc_traffic_bytes("rank_update_kernel") if args.workload == "C3" else None,
+                               "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes committed under profiles/ "
+                                               "(not collectable inside this process); algorithmic bytes: read P + Y, write P",
+                               "algorithmic_bytes_per_launch": 8.0 * (2.0 * n * n + n * r),
+                               "algorithmic_flops_per_launch": flops, "launch_us": us, "rank_r": r,
+                               "rank_update_standalone": k10,
+                               "note": "n(n+1)r flops of P - Y Y^T on lower-triangle tile pairs; launch duration from "
+                                       "hipEvents bracketing the kernel on its stream, mean of %d eager frames" % nrep}
         # K8, the factor sweep: r^3/3 + n r^2 flop (SURVEY 8d F_update terms) over its stage time
         us8 = acc["factor_hi_us"]
         rr = 2 * k_hi
@@ -398,7 +514,8 @@ def main():
         out["factor_sweep"] = {"launch_us": us8, "rank_r": rr, "algorithmic_flops": f8,
                                "achieved_TFLOPs": f8 / (us8 * 1e-6) * 1e-12 if us8 > 0 else 0.0,
                                "frac_of_fp64_mfma_peak": (f8 / (us8 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS) if us8 > 0 else 0.0,
-                               "note": "HI pass; bound by the serial pivot chain (r dependent pivots), not by the matrix pipe"}
+                               "note": "HI pass; bound by the serial pivot chain (r dependent pivots), not by the matrix pipe"
+                                       + ("; the stage time includes the rank update that runs inside the same launch" if mode == 2 else "")}
         if not args.no_extras and world == 1:
             out["probes"] = {"mfma_f64_16x16x4_1wave_per_simd": ctx.mfma_f64_probe(1, 0),
                              "mfma_f64_16x16x4_2waves_per_simd": ctx.mfma_f64_probe(2, 0),

@@ -260,22 +260,26 @@ int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t h
 int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph);
 
 /* Diagnostics of the resident pipeline since rslam_create (any pointer may be NULL): hipGraph captures
- * (a change of the launch sequence re-captures); update stages that had to be re-run -- because the
- * launch-per-step factor sweep (large systems) had been enqueued too short for the frame's inlier count, or
- * because a hand-over of the persistent sweep ran into its bounded wait (its workgroups were not all resident:
- * another user of the GPU), in which case the stage is re-run with the launch-per-step sweep and the context keeps
- * to that sweep for the next 64 frames. */
+ * (a change of the launch sequence re-captures); update stages that had to be re-run -- because a hand-over of the
+ * persistent sweep (or of its tile workers) ran into its bounded wait (its workgroups were not all resident: another user
+ * of the GPU), in which case the stage is re-run with the launch-per-step sweep and the context keeps to that sweep for the
+ * next 64 frames (doubling while the timeouts keep coming), or because the Jnorm hand-over of the stand-alone rank update
+ * timed out (re-run with the x-update riders dispatched first). */
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 
 /* Block until the stream is idle; returns the device-side status of the
  * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...).
  * Frames may be enqueued back to back without rslam_sync: the factor sweep of an update is one persistent launch
- * sized for the largest inlier count the frame can have.  Only systems too large for that path (more than 16 column
- * blocks of S or more 16-row strips than compute units, e.g. 1000 landmarks) size their launch sequence from the
- * previous frame's inlier counts; there an overflow is detected on the device and the update stage re-run by the next
- * rslam_sync / rslam_fetch_* / rslam_ekf_prediction / rslam_map_* call, all of which check the frame in flight first --
- * but a further rslam_step_* enqueued on top of an unchecked frame starts from a posterior that may still be re-run:
- * sync such pipelines once per frame. */
+ * sized for the largest inlier count the frame can have, and it carries the x / covariance update of the same stage
+ * (no dependence on the previous frame, nothing to re-capture).  The status of a frame nobody synchronised on is not
+ * lost: the next rslam_sync / rslam_fetch_* reports the smallest status seen since the last report, and
+ * rslam_ekf_prediction / rslam_map_* / rslam_load_measurements check the frame in flight first.  A bounded wait inside that
+ * launch that runs out (its workgroups were not all resident: another user of the GPU) is such a status: the call that
+ * sees it re-runs the update stage on the launch-per-step path (see rslam_get_counters).
+ * Systems too large for that path (more than 16 column blocks of S or more 16-row strips than compute units, e.g. 1000
+ * landmarks) run one launch sequence per block step whose length the HOST reads from the device (one integer after the
+ * consensus, one after the rescue gate): rslam_step_frame / rslam_step_update block for those two round trips there and such
+ * frames are never replayed from a hipGraph. */
 int rslam_sync(rslam_ctx* ctx);
 
 /* Results of the last frame (host pointers; any may be NULL). Synchronises. */
@@ -303,6 +307,11 @@ int rslam_k_rank_update(rslam_ctx* ctx, int32_t n, int32_t r,
                         const double* dA, int32_t lda,
                         const double* dY, int32_t ldy,
                         double* dC, int32_t ldc);
+
+/* The same kernel timed on its own (roofline measurement): `reps` back-to-back launches on context-owned buffers of
+ * the shape (n, r), bracketed by hipEvents on the context's stream; *us_per_launch = mean duration of one launch.  In the
+ * frame itself the rank update of systems up to ~3000 states runs inside the factor sweep's launch (see rslam_sync). */
+int rslam_k_rank_update_time(rslam_ctx* ctx, int32_t n, int32_t r, int32_t reps, double* us_per_launch);
 
 /* C(m x n) = alpha * A(m x k) * B(n x k)^T + beta * C, dense FP64 MFMA GEMM
  * (the dense form of P*H^T, Tracking.cpp:42,420-421).  All dimensions must be

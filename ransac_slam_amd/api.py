@@ -12,7 +12,8 @@ import numpy as np
 from .ctypes_defs import Config, Layout, StageTimes, make_layout
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librslam_hip.so")
+# (RSLAM_HIP_LIB: another build of the same library, for A/B measurements of kernel variants -- scripts/ab_frame.py)
+LIB_PATH = os.environ.get("RSLAM_HIP_LIB", os.path.join(_HERE, "librslam_hip.so"))
 _lib = None
 
 _dp = C.POINTER(C.c_double)
@@ -60,6 +61,7 @@ SYMBOLS = {
     "rslam_fetch_supports": (C.c_int, [C.c_void_p, _i32p, _u64p, _i32p]),
     "rslam_k_rank_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_int32]),
+    "rslam_k_rank_update_time": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rslam_k_gemm_nt": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32]),
     "rslam_k_mfma_f64_peak": (C.c_int, [C.c_void_p, _dp]),
@@ -86,6 +88,8 @@ def lib():
                 "(the HIP extension is mandatory, there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if "RSLAM_HIP_LIB" in os.environ and not hasattr(L, name):
+                continue                      # an older build under A/B measurement may lack the newest entry points
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
@@ -357,6 +361,12 @@ class RslamHip:
         _chk(lib().rslam_k_rank_update(self._h, n, r, C.c_void_p(dA), lda, C.c_void_p(dY), ldy, C.c_void_p(dC), ldc),
              "rslam_k_rank_update")
 
+    def k_rank_update_time(self, n, r, reps=20):
+        """mean duration (us) of one stand-alone rank-update launch of shape (n, r), hipEvents on the context's stream"""
+        v = C.c_double()
+        _chk(lib().rslam_k_rank_update_time(self._h, n, r, reps, C.byref(v)), "rslam_k_rank_update_time")
+        return v.value
+
     def k_gemm_nt(self, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc):
         _chk(lib().rslam_k_gemm_nt(self._h, m, n, k, alpha, C.c_void_p(dA), lda, C.c_void_p(dB), ldb, beta,
                                    C.c_void_p(dC), ldc), "rslam_k_gemm_nt")
@@ -379,6 +389,26 @@ class RslamHip:
         return d
 
     # ---- diagnostics (not part of include/rslam.h) ---------------------------
+    def debug_update_mode(self):
+        """0 launch-per-step sweep, 1 persistent sweep + stand-alone rank update, 2 update inside the persistent sweep launch"""
+        fn = lib().rslam_debug_update_mode
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p]
+        return fn(self._h)
+
+    def debug_sweep_stamps(self):
+        """one eager frame with wall-clock stamps inside the persistent sweep (last sweep launch = HI pass) ->
+        int64 array [who][block/step][slot] (100 MHz ticks; scripts/sweep_stamps.py explains the slots)"""
+        fn = lib().rslam_debug_sweep_stamps
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        _chk(fn(self._h, None, 1), "rslam_debug_sweep_stamps")
+        self.step_frame(False); self.sync()
+        buf = np.zeros(6 * 16 * 8 + 512, np.uint64)
+        _chk(fn(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), 0), "rslam_debug_sweep_stamps")
+        self.wg_start_end = buf[768:].reshape(2, 256).astype(np.int64)      # per workgroup of the launch
+        return buf[:768].reshape(6, 16, 8).astype(np.int64)
+
     def debug_score_residuals(self):
         """(m, m) squared residuals the scoring kernel compares with sigma_z^2: row = matched rank of the hypothesised
         feature, column = matched rank of the scored one (resident frame, after its scoring stage ran)"""

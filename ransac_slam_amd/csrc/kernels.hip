@@ -730,12 +730,20 @@ __device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_i
         if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
         if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // (no hardware fence: see cd_post -- the hand-over is LDS only, served in order; the poll's value has been waited for)
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 
+// Publish: what this wave wrote to LDS, then the flag.  Everything handed over between the waves of the pipeline lives in
+// LDS, and LDS executes a wave's operations in the order they were issued: the flag store cannot overtake the data stores in
+// front of it, and a consumer that has SEEN the flag issues its data reads behind that.  So neither side needs a hardware
+// fence -- a compiler barrier keeps the program order.  The workgroup-scope release / acquire fences that stood here lower to
+// s_waitcnt vmcnt(0) lgkmcnt(0): a wait for the LDS round trip on the publishing side (on the panel wave: on the chain) and,
+// worse, for every outstanding GLOBAL access of the wave -- the T waves of the persistent sweep keep hand-over polls and
+// operand loads in flight across pivot steps, and each such wait stalled their step, and with it the chain, for a memory latency.
 __device__ __forceinline__ void cd_post(CdShared& sh, int flag, int value)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(&sh.flags[flag], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -1427,6 +1435,8 @@ trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
 // ---------------------------------------------------------------------------
 // optional time stamps (100 MHz wall clock) of the persistent sweep: dbg[who][block/step][slot], see scripts/sweep_stamps.py
 constexpr int SWD_WHO = 6, SWD_K = 16, SWD_SLOT = 8;      // who 5: tile worker 0
+constexpr int SWD_WG = 256;                                // behind the [who][k][slot] stamps: start and end of every workgroup
+constexpr int SWD_TOTAL = SWD_WHO * SWD_K * SWD_SLOT + 2 * SWD_WG;
 __device__ __forceinline__ void sw_stamp(unsigned long long* dbg, int who, int k, int slot, int tid = 0)
 {
     if (dbg && (int)threadIdx.x == tid && k < SWD_K) dbg[(who * SWD_K + k) * SWD_SLOT + slot] = wall_clock64();
@@ -2370,7 +2380,7 @@ __device__ __forceinline__ void wk_block(TgAcc (&acc)[WK_SLOTS], const WkTile (&
 
 __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int r_total, int rp_blocks, long ldA, const double* Ypanel,
                                                   const WorkerArgs& wk, SweepFlags* fl, const int32_t* __restrict__ sel, int slot_k,
-                                                  int32_t* status, double* lds, int* abort, unsigned long long* dbg)
+                                                  int32_t* status, double* lds, int* abort, unsigned long long* dbg, int exp_mask)
 {
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), half = wave >> 2, wave4 = wave & 3;
@@ -2388,20 +2398,59 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
     if (n_wg == 0) return;
     const bool timing = dbg && widx == 0;
     if (timing && t == 0) dbg[(5 * SWD_K + 0) * SWD_SLOT + 0] = wall_clock64();
-    // ---- accumulators = 1/2 (P + P^T) of the tile, in the MFMA result layout (tg_acc_to_lds): 128-byte row segments of
-    // both tiles of the pair.  The HI pass reads what the LI pass wrote -- mirrored pairs, exactly symmetric off the
-    // diagonal tiles -- so there the mirror tile need not be read.
+    // ---- accumulators = 1/2 (P + P^T) of the tile, in the MFMA result layout (tg_acc_to_lds).  The HI pass reads what the
+    // LI pass wrote -- mirrored pairs, exactly symmetric off the diagonal tiles -- so there the mirror tile need not be read
+    // and the tile comes straight from memory (128-byte row segments, under the wait for the first column block).
     const bool li_wrote = wk.li_done_slot >= 0 && sel[wk.li_done_slot] > 0;
+    const bool staged = !li_wrote && nblk == 1;
     TgAcc acc[WK_SLOTS];
+    double* hbase = lds + (size_t)half * TD_LDS_DOUBLES;
     {
         const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+        const int t4 = t & 255, row4 = t4 & 63, g4 = t4 >> 6;
+        double* Cs = hbase;                 // tile (bi,bj) as [col][row], tile (bj,bi) as [col][row] behind it
+        double* Ts = hbase + TS_DOUBLES;
 #pragma unroll
         for (int slot = 0; slot < WK_SLOTS; ++slot) {
             tg_zero(acc[slot]);
-            if (!tl[slot].have) continue;
-            const bool mirror_known = li_wrote && tl[slot].bi != tl[slot].bj;
             const double* Pij = wk.Pin + 64L * tl[slot].bi + 64L * tl[slot].bj * wk.ldp;
             const double* Pji = wk.Pin + 64L * tl[slot].bj + 64L * tl[slot].bi * wk.ldp;
+            if (staged) {
+                // both tiles of the pair, each in 512-byte column runs, through LDS (the mirror tile is needed transposed):
+                // a system of one diagonal block is done in microseconds, the pass is then a stream over P and this read is
+                // on its critical path (elsewhere the tiles arrive under the wait for the first column block)
+                if (slot >= n_wg) continue;                          // (uniform: the barriers below are taken by both engines)
+                if (tl[slot].have) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {                    // 16 loads of the thread in flight at once, twice
+                        double pa[8], pb[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            pa[q] = Pij[row4 + (long)(g4 + 4 * (8 * h + q)) * wk.ldp];
+                            pb[q] = Pji[row4 + (long)(g4 + 4 * (8 * h + q)) * wk.ldp];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            Cs[(g4 + 4 * (8 * h + q)) * TS_LD + row4] = pa[q];
+                            Ts[(g4 + 4 * (8 * h + q)) * TS_LD + row4] = pb[q];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tl[slot].have) {
+#pragma unroll
+                    for (int mi = 0; mi < TG_MI; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = mi * 16 + 4 * blk + i, col = wave4 * 16 + 4 * ((blk - q) & 3) + j;
+                            acc[slot][mi][0][q] = 0.5 * Cs[col * TS_LD + row] + 0.5 * Ts[row * TS_LD + col];
+                        }
+                }
+                __syncthreads();
+                continue;
+            }
+            if (!tl[slot].have) continue;
+            const bool mirror_known = li_wrote && tl[slot].bi != tl[slot].bj;
 #pragma unroll
             for (int mi = 0; mi < TG_MI; ++mi)
 #pragma unroll
@@ -2419,8 +2468,8 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
         const WkTile tt = wk_tile(wk, widx + s6 * W, ntiles);
         if (tt.have) my_flag = 4 * rp_blocks + 4 * (sub < 4 ? tt.bi : tt.bj) + (sub & 3);
     }
-    double* hbase = lds + (size_t)half * TD_LDS_DOUBLES;
     const double* Y = Ypanel + RP;
+    const bool k11 = wk.T && sel[slot_k] != 0;
     for (int k = 0; k < nblk; ++k) {
         if (timing && t == 0 && k < SWD_K) dbg[(5 * SWD_K + k) * SWD_SLOT + 1] = wall_clock64();
         if (t < 64) {
@@ -2441,22 +2490,25 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
         if (timing && t == 0 && k < SWD_K) dbg[(5 * SWD_K + k) * SWD_SLOT + 3] = wall_clock64();
     }
     // ---- epilogue per tile: through LDS (coalesced stores of the tile and of its mirror); K11 on the first block column
+    // (Jnorm congruence on rows / columns 3..6, ExtendKF.cpp:629-634).  The 27.5 MB all workers write at this point are what
+    // the epilogue costs (HBM write rate); storing a tile straight from the accumulators behind its last chunk, under the
+    // next tile's MFMAs, was tried and is slower: the chunk barrier's vmcnt(0) (it waits for the LDS-DMA) drains those stores too.
     const int t4 = t & 255, row = t4 & 63, g4 = t4 >> 6;
     double* Cs = hbase;
-    const bool k11 = wk.T && sel[slot_k] != 0;
     static_for<0, WK_SLOTS>([&](auto S) {
         constexpr int slot = decltype(S)::value;
         if (slot < n_wg) {
-            const bool have = tl[slot].have;
+            const bool mine = tl[slot].have;
+            const bool fix = mine && k11 && tl[slot].bj == 0;
             const int bi = tl[slot].bi, bj = tl[slot].bj;
             __syncthreads();                                         // the operand buffers / the previous tile's image are free
-            if (have) tg_acc_to_lds_w(acc[slot], Cs, 1.0, wave4);
+            if (mine) tg_acc_to_lds_w(acc[slot], Cs, 1.0, wave4);
             __syncthreads();
-            if (have && k11 && bj == 0 && t4 < 64) {
+            if (fix && t4 < 64) {
                 // Jnorm comes from the strip of state rows 0..15 of this launch (xacc_finish), long ago
                 int spins = 0;
                 while (ld_flag(wk.xu_flag) < wk.token) {
-                    if (++spins > (1 << 22)) { atomicMin(status, -38); break; }
+                    if (++spins > (1 << 16)) { atomicMin(status, -38); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 double T[16];
@@ -2498,7 +2550,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
                 }
             }
             __syncthreads();
-            if (have) {
+            if (mine) {
                 double* Cij = wk.Pout + 64L * bi + 64L * bj * wk.ldo;
                 double* Cji = wk.Pout + 64L * bj + 64L * bi * wk.ldo;
 #pragma unroll 4
@@ -2527,6 +2579,11 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int s_wk_abort;
+    if (dbg && threadIdx.x == 0 && blockIdx.x < SWD_WG) dbg[SWD_WHO * SWD_K * SWD_SLOT + blockIdx.x] = wall_clock64();
+    struct EndStamp {       // (diagnostic: when thread 0 of the workgroup leaves, whatever the path)
+        unsigned long long* p;
+        __device__ ~EndStamp() { if (p) *p = wall_clock64(); }
+    } end_stamp{(dbg && threadIdx.x == 0 && blockIdx.x < SWD_WG) ? dbg + SWD_WHO * SWD_K * SWD_SLOT + SWD_WG + blockIdx.x : nullptr};
     // The hand-over flags are double-buffered between the two sweeps of a frame: this launch uses `flags` (all zero:
     // the previous sweep cleared them) and clears `flags_other` for the next one -- nobody is using that set now.
     if (blockIdx.x == 0 && threadIdx.x < SWEEP_FLAG_INTS) flags_other[threadIdx.x] = 0;
@@ -2549,10 +2606,10 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
         if (!(exp_mask & 16)) cd_chain_persistent(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, NP / 16 + 1);
         return;
     }
-    int widx = -1;                                            // tile worker index, or -1: this workgroup is a strip of the system
     if (fused) {
         // Workers: the blocks behind the strips, and the strips that hold no rows of this system -- S row blocks 0, 1 (the
         // lower strips assemble those for the chain) and nblk .. (padding), and the three strips below nu^T.
+        int widx = -1;
         const int extra = (int)gridDim.x - 1 - nstrips;
         const int lo_blocks = rp_blocks < 2 ? rp_blocks : 2, hi0 = nblk > 2 ? nblk : 2;
         const int n_idle_s = 4 * (lo_blocks + (rp_blocks > hi0 ? rp_blocks - hi0 : 0));
@@ -2562,8 +2619,23 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
             if (b < rp_blocks) { if (b < 2) widx = extra + strip; else if (b >= hi0) widx = extra + 4 * lo_blocks + (strip - 4 * hi0); }
             else if (b == (int)(ldA / 64) - 1 && (strip & 3) != 0) widx = extra + n_idle_s + (strip & 3) - 1;
         }
+        // A system of one diagonal block keeps its P H^T / nu strips busy for a few microseconds only: they join the workers
+        // afterwards (the covariance pass is then a stream over P shared by every compute unit of the device).
+        const int n_late = single ? NP / 16 + 1 : 0;
+        const int n_workers = extra + n_idle_s + 3 + n_late;
         if (widx >= 0) {
-            sweep_tile_worker(widx, extra + n_idle_s + 3, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg);
+            sweep_tile_worker(widx, n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg, exp_mask);
+            return;
+        }
+        if (single && bx <= nstrips) {
+            // (a second inlined copy of the worker: one call site for both measured 3 us per frame slower -- the allocator then
+            //  keeps the strip's registers alive across the worker)
+            const int strip = bx - 1;
+            sweep_strip<NJ>(A, ldA, rp_blocks, nblk, strip, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k,
+                            (exp_mask & 8) != 0, wk, exp_mask);
+            __syncthreads();                                  // the strip's LDS is free
+            sweep_tile_worker(extra + n_idle_s + 3 + (strip - 4 * rp_blocks), n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k,
+                              status, lds, &s_wk_abort, nullptr, exp_mask);
             return;
         }
     }
@@ -2617,9 +2689,9 @@ int init_kernel_attributes()
 // a second), at most 16 column blocks (the accumulators of a strip are a compile-time array).
 // diagnostic time stamps of the persistent sweep (the last launch wins); off unless a buffer is installed
 static unsigned long long* g_sweep_dbg = nullptr;
-int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nullable = only (un)install */, int enable)
+int debug_sweep_stamps(unsigned long long* out /* SWD_TOTAL, nullable = only (un)install */, int enable)
 {
-    const size_t bytes = sizeof(unsigned long long) * SWD_WHO * SWD_K * SWD_SLOT;
+    const size_t bytes = sizeof(unsigned long long) * SWD_TOTAL;
     if (enable && !g_sweep_dbg) {
         if (hipMalloc((void**)&g_sweep_dbg, bytes) != hipSuccess) { g_sweep_dbg = nullptr; return -1; }
         (void)hipMemset(g_sweep_dbg, 0, bytes);
@@ -2632,7 +2704,8 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_WHO * SWD_K * SWD_SLOT, nu
 // RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
 // shared route too, bit 3 no register-only route for systems of <= 4 rows, bit 4 fault injection (the chain
 // workgroup does not run), bit 5 fault injection (the strips never announce their Y blocks: tile workers and the x update
-// run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep);
+// run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep), bit 8 the time
+// stamps of scripts/sweep_stamps.py come from the LI pass instead of the HI pass;
 // set_sweep_exp_mask overrides the environment (tests)
 static int g_sweep_exp_override = -1;
 void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }
@@ -2697,10 +2770,11 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
         // fused: one workgroup per compute unit -- the ones behind the strips are tile workers
         const dim3 grid(wa.Pout ? device_cus() : 1 + d.ldA / 16), block(CD_THREADS);
         const int exp_mask = sweep_exp_mask();             // measurement / fault-injection switches
+        const bool stamp_this = ((exp_mask & 256) != 0) == (slot_k == SEL_K_LI);      // time stamps: the HI pass, or (bit 8) the LI pass
         const int set = (slot_k == SEL_K_LI) ? 0 : 1;              // the LI and the HI sweep of a frame alternate between the two flag sets
         int32_t* fl_cur = flags + set * SWEEP_FLAG_INTS;
         int32_t* fl_other = flags + (1 - set) * SWEEP_FLAG_INTS;
-#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, g_sweep_dbg, exp_mask, wa)
+#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, stamp_this ? g_sweep_dbg : nullptr, exp_mask, wa)
         if (rp_blocks <= 4) SWP_LAUNCH(4);
         else if (rp_blocks <= 8) SWP_LAUNCH(8);
         else if (rp_blocks <= 12) SWP_LAUNCH(12);

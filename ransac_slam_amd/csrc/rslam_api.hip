@@ -99,11 +99,6 @@ struct rslam_ctx {
     int g1_hb = -1, g1_he = -1;
     const void* g1_sup = nullptr;
     const void* g2_sup = nullptr;
-    // Factor-sweep launch sizing: the number of block steps enqueued per update follows the
-    // previous frame's inlier counts (+1 block of slack); the device flags an overflow
-    // (STATUS_SWEEP_CAP) and the update stage is then re-run with the full-length sequence.
-    int cap_li = 1 << 20, cap_hi = 1 << 20;
-    int calm_li = 0, calm_hi = 0;
     const int32_t* last_sup = nullptr;
     int reruns = 0;
     int graph_captures = 0;
@@ -133,8 +128,10 @@ static void mark_update_enqueued(rslam_ctx* c, const int32_t* d_sup)
 {
     const int rp_blocks = c->RP / 64;
     c->last_sup = d_sup;
-    // the persistent sweep is one launch sized for the largest inlier count: nothing to overflow
-    c->sweep_can_overflow = !sweep_is_persistent(c) && (c->cap_li < rp_blocks || c->cap_hi < rp_blocks);
+    // the persistent sweep is one launch sized for the largest inlier count, the launch-per-step sweep is sized by the
+    // host from this frame's own counts: nothing to overflow
+    (void)rp_blocks;
+    c->sweep_can_overflow = false;
     c->frame_checked = false;
     c->rep_status = c->rep_front = c->rep_sticky = 0;
     c->have_post = true;
@@ -568,12 +565,22 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
         c->pht_done = true;
     }
     const bool persistent = sweep_is_persistent(c);
-    const int cap_li = persistent ? (1 << 20) : c->cap_li, cap_hi = persistent ? (1 << 20) : c->cap_hi;
+    int cap_li = 1 << 20, cap_hi = 1 << 20;
     // K5 consensus (Tracking.cpp:507-537)
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
                      c->cfg.sigma_z, c->L, cap_li, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
                      c->cfg.adaptive, c->cfg.n_hyp_init);
     mark(c, EV_SELECT);
+    // Systems too large for the persistent sweep (more 16-row strips than compute units, e.g. 1000 landmarks) run one launch
+    // sequence per block step, and how many steps an update needs is only known on the device.  The host reads that one
+    // integer here (a ~15 us round trip in a frame of milliseconds) and enqueues exactly that many: no sizing from the
+    // previous frame, no overflow, no re-run, no hipGraph re-capture.  Such frames are therefore not captured into graphs.
+    if (!persistent) {
+        int32_t nb = 0;
+        HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_LI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        cap_li = nb;
+    }
     // low-innovation update (ExtendKF.cpp:559-596)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
     int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, cap_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
@@ -587,6 +594,12 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
                        cap_hi, c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
+    if (!persistent) {
+        int32_t nb = 0;
+        HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_HI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        cap_hi = nb;
+    }
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
     if (c->RP > 0)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
@@ -643,22 +656,6 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         rc = read_status_raw(c, sel);
         if (rc) return rc;
     }
-    if (sel[SEL_CAP_FLAG] != 0 && c->last_sup) {
-        c->cap_li = c->cap_hi = 1 << 20;
-        invalidate_graph(c);
-        ++c->reruns;
-        const int timing = c->timing; c->timing = 0;
-        // everything the shortened update stage left behind is void (its rank update consumed columns the sweep never
-        // produced, so even a "not SPD" of the second pass may be spurious); the front-stage status is kept
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_CAP_FLAG, 0, sizeof(int32_t), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));     // Jnorm hand-over of the rank-update launches
-        rc = enqueue_update(c, c->last_sup);
-        c->timing = timing;
-        if (rc) return rc;
-        rc = read_status_raw(c, sel);
-        if (rc) return rc;
-    }
     // (codes -31..-38 and the chain's per-block -36-10k: waits of the persistent sweep and its tile workers; -39 is the
     //  rider hand-over of the stand-alone rank update, handled below)
     const bool sweep_timeout = sel[SEL_STATUS] <= -30 && sel[SEL_STATUS] != -39;
@@ -676,7 +673,6 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         c->steps_frames_left = 64 << (c->consecutive_fallbacks < 6 ? c->consecutive_fallbacks : 6);
         ++c->consecutive_fallbacks;
         ++c->sweep_fallbacks;
-        c->cap_li = c->cap_hi = 1 << 20;
         invalidate_graph(c);
         const int timing = c->timing; c->timing = 0;
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
@@ -703,24 +699,6 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     if (sel[SEL_STATUS] <= -30) {                 // (still: which wait it was is kept for diagnosis)
         c->last_raw_status = sel[SEL_STATUS];
         sel[SEL_STATUS] = RSLAM_ERR_HIP;
-    }
-    if (c->have_meas && c->last_sup && sel[SEL_STATUS] == 0 && !sweep_is_persistent(c)) {
-        // grow at once (an overflow costs a re-run of the update stage); shrink at once when two or more block
-        // steps are wasted, and by the last one only after the count has stayed lower for 8 frames (each change
-        // of the launch sequence re-captures the hipGraphs; every empty step is two ~4.5 us launches)
-        // room for 8 more inlier features than this frame had (16 rows), not a whole spare block: every block
-        // step that turns out empty is a ~4.5 us launch
-        auto adapt = [&](int& cap, int& calm, int k) {
-            int want = (2 * k + 16 + 63) / 64;
-            if (want < 1) want = 1;
-            if (want > rp_blocks) want = rp_blocks;
-            const int cur = cap < rp_blocks ? cap : rp_blocks;
-            if (want > cur) { cap = want; calm = 0; invalidate_graph(c); }
-            else if (want < cur) { if (cur - want >= 2 || ++calm >= 8) { cap = want; calm = 0; invalidate_graph(c); } }
-            else calm = 0;
-        };
-        adapt(c->cap_li, c->calm_li, sel[SEL_K_LI]);
-        adapt(c->cap_hi, c->calm_hi, sel[SEL_K_HI]);
     }
     if (sel_host) memcpy(sel_host, sel, sizeof(sel));
     c->frame_checked = true;
@@ -1261,7 +1239,7 @@ extern "C" int rslam_step_frame(rslam_ctx* c, int32_t use_graph)
     if (!c) return RSLAM_ERR_ARG;
     if (!c->have_state || !c->have_meas) return RSLAM_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
-    if (!use_graph || c->timing) return enqueue_frame(c);
+    if (!use_graph || c->timing || !sweep_is_persistent(c)) return enqueue_frame(c);      // (host-sized update stage: never captured)
     const int rc = replay(c, 0, [&]() { return enqueue_frame(c); });
     if (rc) return rc;
     c->predicted = true; c->pht_done = true; c->patches_valid = false;
@@ -1290,7 +1268,7 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
     }
     if (!c->predicted) return RSLAM_ERR_STATE;
     auto work = [&]() { return enqueue_update(c, d_supports); };
-    if (!use_graph || c->timing) return work();
+    if (!use_graph || c->timing || !sweep_is_persistent(c)) return work();
     if (c->g2_sup != d_supports) { c->graph_valid[2] = false; c->g2_sup = d_supports; }
     const int rc = replay(c, 2, work);
     if (rc) return rc;
@@ -1415,6 +1393,36 @@ extern "C" int rslam_k_rank_update(rslam_ctx* c, int32_t n, int32_t r, const dou
     return RSLAM_OK;
 }
 
+// K10 on its own: `reps` back-to-back launches of the stand-alone rank update on context-owned buffers of the given shape
+// (P: round_up(n, 64)^2, Y: round_up(n, 64) x round_up(r, 32), constant fill: the kernel's time does not depend on the
+// values), bracketed by hipEvents on the context's stream.  us_per_launch = mean duration of one launch.
+extern "C" int rslam_k_rank_update_time(rslam_ctx* c, int32_t n, int32_t r, int32_t reps, double* us_per_launch)
+{
+    if (!c || !us_per_launch || n <= 0 || r <= 0 || reps <= 0) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int NP = round_up(n, 64), K = round_up(r, TG_KC_HOST);
+    double *P = nullptr, *Y = nullptr;
+    HIPCHK(hipMalloc((void**)&P, sizeof(double) * (size_t)NP * NP));
+    if (hipMalloc((void**)&Y, sizeof(double) * (size_t)NP * K) != hipSuccess) { (void)hipFree(P); return RSLAM_ERR_HIP; }
+    hipStream_t s = c->stream;
+    (void)hipMemsetAsync(P, 0, sizeof(double) * (size_t)NP * NP, s);
+    (void)hipMemsetAsync(Y, 0, sizeof(double) * (size_t)NP * K, s);
+    const int32_t* order = tile_order(c, NP);
+    for (int i = 0; i < 3; ++i) launch_rank_update(s, NP, P, NP, Y, NP, c->d_sel.p, 0, K, P, NP, order, nullptr, 0, nullptr);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    for (int i = 0; i < reps; ++i) launch_rank_update(s, NP, P, NP, Y, NP, c->d_sel.p, 0, K, P, NP, order, nullptr, 0, nullptr);
+    (void)hipEventRecord(b, s);
+    const hipError_t e = hipEventSynchronize(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(P); (void)hipFree(Y);
+    if (e != hipSuccess) return RSLAM_ERR_HIP;
+    *us_per_launch = (double)ms * 1e3 / reps;
+    return RSLAM_OK;
+}
+
 extern "C" int rslam_k_gemm_nt(rslam_ctx* c, int32_t m, int32_t n, int32_t k, double alpha, const double* dA,
                                int32_t lda, const double* dB, int32_t ldb, double beta, double* dC, int32_t ldc)
 {
@@ -1519,6 +1527,15 @@ extern "C" int rslam_debug_distort(rslam_ctx* c, int32_t n, const double* uv, do
 // diagnostic (not part of include/rslam.h): time stamps of the persistent factor sweep, see scripts/sweep_stamps.py
 namespace rslam { int debug_sweep_stamps(unsigned long long* out, int enable); }
 extern "C" int rslam_debug_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
+// how the update stage of the loaded frame shape runs: 0 launch-per-step sweep + stand-alone rank update, 1 persistent sweep +
+// stand-alone rank update, 2 persistent sweep with the x / covariance update inside its launch
+extern "C" int rslam_debug_update_mode(rslam_ctx* c)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
+    if (!sweep_is_persistent(c)) return 0;
+    return sweep_fused_eligible(d) ? 2 : 1;
+}
 // diagnostics / fault injection (not part of include/rslam.h): RSLAM_SWEEP_EXP switches from the host, -1 = environment
 extern "C" int rslam_debug_set_sweep_exp(int mask) { rslam::set_sweep_exp_mask(mask); return RSLAM_OK; }
 // fault injection (tests), per context: riders of the stand-alone rank update that sit behind the tiles never publish Jnorm

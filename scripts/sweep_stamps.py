@@ -18,7 +18,11 @@ ap.add_argument("--compat", type=int, default=1)
 ap.add_argument("--L", type=int, default=300)
 ap.add_argument("--H", type=int, default=1000)
 ap.add_argument("--seed", type=int, default=2)
+ap.add_argument("--li", action="store_true", help="stamps of the LI pass (RSLAM_SWEEP_EXP bit 8) instead of the HI pass")
 a = ap.parse_args()
+if a.li:
+    api.lib().rslam_debug_set_sweep_exp.argtypes = [C.c_int]
+    api.lib().rslam_debug_set_sweep_exp(256)
 fr = make_frame(L=a.L, H=a.H, seed=a.seed)
 ctx = api.RslamHip(default_config(compat=a.compat, adaptive=0))
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
@@ -31,8 +35,10 @@ for _ in range(3):
     ctx.step_frame(False); ctx.sync()
 assert fn(ctx._h, None, 1) == 0
 ctx.step_frame(False); ctx.sync()
-buf = np.zeros(WHO * K * SLOT, np.uint64)
+buf = np.zeros(WHO * K * SLOT + 512, np.uint64)
 assert fn(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), 0) == 0
+wg = buf[WHO * K * SLOT:].reshape(2, 256).astype(np.int64)
+buf = buf[:WHO * K * SLOT]
 r = ctx.fetch_results(want_P=False)
 print("n_li", r["n_li"], "n_hi", r["n_hi"])
 st = buf.reshape(WHO, K, SLOT).astype(np.int64)
@@ -55,3 +61,11 @@ for k in range(K):
     if st[5, k, 1] == 0:
         break
     print(f"  block {k:2d}: " + " ".join(f"{us(v):8.2f}" for v in st[5, k, 1:4]))
+live = wg[0] > 0
+if live.any():
+    s0 = wg[0][live].min()
+    print("workgroups: first start %.2f, last start %.2f, first end %.2f, LAST END %.2f (workgroup %d); chain reference t0 = %.2f after the first start"
+          % ((s0 - t0) / 100.0, (wg[0][live].max() - t0) / 100.0, (wg[1][live].min() - t0) / 100.0, (wg[1][live].max() - t0) / 100.0,
+             int(np.argmax(np.where(live, wg[1], 0))), (t0 - s0) / 100.0))
+    order = np.argsort(-np.where(live, wg[1], 0))[:8]
+    print("  latest workgroups (block index: end):", ", ".join("%d: %.2f" % (int(i), (wg[1][i] - t0) / 100.0) for i in order))

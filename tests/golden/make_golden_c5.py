@@ -4,16 +4,16 @@ through the CPU oracle, so that the device's C5 frame is checked against the ora
 The posterior covariance is 289 MB and is not committable; the fixture keeps what pins it: every integer output
 (supports, 64-bit masks, consensus scalars, LI / HI flags), x_k_k, the whole diagonal of p_k_k, 8192 seeded sample
 entries (half of them in the rows of the quaternion block, whose magnitudes are six orders below the largest
-entry), the Frobenius norm and the trace.  Inputs are NOT stored: they are `make_frame(L=1000, H=1000, seed=4)`
-(ransac_slam_amd/synth.py, the generator of every other C5 figure); a digest of them is, so that a drift of the
-generator is noticed.
+entry), the Frobenius norm and the trace.  The inputs are `make_frame(L=1000, H=1000, seed=4)` (ransac_slam_amd/synth.py,
+the generator of every other C5 figure) and are stored in c5_inputs.npz -- the prior covariance in the factored form the
+generator builds it from, P = sym(U U^T) + diag(D) with U n x 13 (the generator's BLAS products round differently from
+machine to machine, so regenerating the frame elsewhere would not give bit-identical inputs).
 
 Runs the structured oracle (identical arithmetic, structural zeros of H skipped, repeated hypotheses cached) in its
 OpenMP build on all host cores: a few minutes.
 
     make -C oracle omp && python tests/golden/make_golden_c5.py
 """
-import hashlib
 import os
 import subprocess
 import sys
@@ -38,16 +38,10 @@ sys.path.insert(0, HERE)
 from c5_samples import sample_indices                     # noqa: E402  (shared with tests/test_gpu_parity.py)
 
 
-def input_digest(fr, ic):
-    h = hashlib.sha256()
-    for a in (fr.types, fr.x_pred, np.asarray(fr.P_pred), fr.z, ic, fr.draws):
-        h.update(np.ascontiguousarray(a).tobytes())
-    return np.frombuffer(h.digest(), np.uint8).copy()
-
-
 def main():
     os.makedirs(os.path.join(HERE, "c5"), exist_ok=True)
     fr = make_frame(L=1000, H=1000, seed=4)
+    ic_saved = None
     for compat in (1, 0):
         t0 = time.time()
         cfg = default_config(compat=compat, adaptive=0)
@@ -59,7 +53,12 @@ def main():
         sm, rm = o.margins()
         P = np.asarray(r["P_new"])
         rows, cols = sample_indices(fr.n)
-        out = dict(compat=np.int32(compat), digest=input_digest(fr, ic), visible=vis, ic=ic, h=h, S=S,
+        if ic_saved is None:
+            ic_saved = ic
+            np.savez_compressed(os.path.join(HERE, "c5", "c5_inputs.npz"), types=fr.types, x_pred=fr.x_pred, z=fr.z, ic=ic,
+                                draws=fr.draws, diagD=fr.diagD, U=fr.U)
+        assert np.array_equal(ic, ic_saved)
+        out = dict(compat=np.int32(compat), visible=vis, ic=ic, h=h, S=S,
                    supports=sup, positions=pos, masks=masks, margins=np.array([sm, rm]),
                    scalars=np.array([r["best_hyp"], r["best_support"], r["hyps_evaluated"]], np.int32),
                    li=r["li"], hi=r["hi"], x_new=r["x_new"], P_diag=np.diag(P).copy(), P_samples=P[rows, cols].copy(),

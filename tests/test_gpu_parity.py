@@ -535,22 +535,24 @@ def test_c3_full_size_against_structured_oracle(hip, oracle_lib, compat):
 @pytest.mark.parametrize("compat", [1, 0])
 def test_c5_against_oracle_fixture(hip, compat):
     """BASELINE config C5 (1000 landmarks, n = 6013, 1000 hypotheses) against the oracle: tests/golden/c5/*.npz hold the
-    structured oracle's outputs on make_frame(L=1000, H=1000, seed=4) (tests/golden/make_golden_c5.py; the 289 MB
-    posterior itself is not committable: its diagonal, 8192 seeded entries -- half of them in the quaternion rows --
-    Frobenius norm and trace are).  This is where the launch-per-step sweep with 25 diagonal blocks and the 95 x 95 tile
-    rank update run (ExtendKF.cpp:597-639 at r ~ 1570)."""
-    import hashlib
+    structured oracle's outputs on make_frame(L=1000, H=1000, seed=4) (tests/golden/make_golden_c5.py) and the inputs,
+    the prior covariance as its factors (the 289 MB posterior itself is not committable: its diagonal, 8192 seeded
+    entries -- half of them in the quaternion rows -- Frobenius norm and trace are).  This is where the launch-per-step
+    sweep with 25 diagonal blocks and the 95 x 95 tile rank update run (ExtendKF.cpp:597-639 at r ~ 1570)."""
+    from types import SimpleNamespace
     sys_path = os.path.join(os.path.dirname(__file__), "golden")
     g = np.load(os.path.join(sys_path, "c5", f"c5_compat{compat}.npz"))
+    gi = np.load(os.path.join(sys_path, "c5", "c5_inputs.npz"))
     import importlib.util
-    spec = importlib.util.spec_from_file_location("make_golden_c5_idx", os.path.join(sys_path, "c5_samples.py"))
+    spec = importlib.util.spec_from_file_location("c5_samples", os.path.join(sys_path, "c5_samples.py"))
     idx = importlib.util.module_from_spec(spec); spec.loader.exec_module(idx)
-    fr = make_frame(L=1000, H=1000, seed=4)
-    ic = g["ic"]
-    dg = hashlib.sha256()
-    for a in (fr.types, fr.x_pred, np.asarray(fr.P_pred), fr.z, ic, fr.draws):
-        dg.update(np.ascontiguousarray(a).tobytes())
-    assert np.array_equal(np.frombuffer(dg.digest(), np.uint8), g["digest"])       # the generator still makes the fixture's inputs
+    # the fixture's inputs; the prior covariance from its stored factors, as the generator builds it (synth.make_frame)
+    P0 = gi["U"] @ gi["U"].T
+    P0[np.diag_indices(len(P0))] += gi["diagD"]
+    P0 = np.asfortranarray(0.5 * (P0 + P0.T))
+    fr = SimpleNamespace(types=gi["types"], x_pred=gi["x_pred"], P_pred=P0, z=gi["z"], draws=gi["draws"], n=len(P0))
+    ic = gi["ic"]
+    assert np.array_equal(ic, g["ic"])
     assert g["margins"].min() > 1e-9                                               # every decision of the oracle has a margin
     c = hip.RslamHip(default_config(compat=compat, adaptive=0))
     c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)

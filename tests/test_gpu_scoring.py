@@ -119,8 +119,9 @@ def test_far_projections_take_the_reference_sequence(hip, oracle_lib):
     neither have the reference's ten: the NON-converged ten-step value is what the reference compares with sigma_z, and
     it can land back inside the image (a huge radial-distortion denominator pulls it towards the principal point), next
     to a measurement.  The scoring kernel therefore switches to the reference's own sequence (distort_fm: ten steps,
-    IEEE divisions) beyond the radius up to which its six steps are at the fixed point: both device forms must then be
-    bit-identical, and equal to the oracle's distort_fm to rounding."""
+    IEEE divisions) beyond the radius up to which its six steps are at the fixed point: both device forms must then agree
+    to rounding (the same source inlined at two places: the compiler contracts multiply-adds differently), and with the
+    oracle's distort_fm."""
     cam = default_camera()
     g = hip.RslamHip(default_config())
     rng = np.random.default_rng(6)
@@ -131,8 +132,9 @@ def test_far_projections_take_the_reference_sequence(hip, oracle_lib):
     a, b = g.debug_distort(uv)
     g.close()
     ref = np.array([oracle_lib.distort_fm(cam, p) for p in uv])
-    assert np.array_equal(a, b)                                   # the scoring form IS the ten-step form out here
+    assert np.max(np.abs(a - b)) <= 1e-10                         # the scoring form IS the ten-step form out here
     assert np.max(np.abs(b - ref)) <= 1e-9                        # (contractive iteration: rounding differences do not grow)
+    assert np.max(np.abs(a - ref)) <= 1e-9
     inside = (ref[:, 0] > 0) & (ref[:, 0] < cam.nCols) & (ref[:, 1] > 0) & (ref[:, 1] < cam.nRows)
     assert inside.sum() > 100                                     # the hazard is real: such values do land inside the image
     # ... where six steps with the same start would have been somewhere else entirely

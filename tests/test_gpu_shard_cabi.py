@@ -113,3 +113,58 @@ def test_cpp_shard_frame_example(oracle_lib, tmp_path, compat):
     assert np.array_equal(li, r0["li"]) and np.array_equal(hi, r0["hi"])
     assert np.max(np.abs(x - r0["x_new"])) <= 1e-9 * max(1.0, np.abs(r0["x_new"]).max())
     assert np.max(np.abs(P - r0["P_new"])) <= 1e-9 * np.abs(r0["P_new"]).max()
+
+
+@pytest.mark.timeout(600)
+def test_cpp_shard_frame_two_ranks_one_device(oracle_lib, tmp_path):
+    """rslam_shard_frame with world = 2: two processes (the C++ example as rank 0 and rank 1), each with its own context and
+    ONE RCCL communicator of two ranks -- both on device 0, the only device of the test box.  If this RCCL refuses two
+    ranks on one device (NCCL's "Duplicate GPU detected": ncclCommInitRank fails on both ranks) the test says so and is
+    skipped: the two-rank slicing / tail padding / consensus replay is then covered over gloo (tests/test_gpu_configs.py,
+    two ranks on one device) and on CPU (tests/test_sharded_gloo.py), the RCCL call itself by the one-rank self-gather."""
+    from ransac_slam_amd import build
+    build.build()
+    exe = build.build_shard_example()
+    fr = make_frame(L=60, H=1001, seed=502, frac_ic=0.9)          # 1001 draws: the second slice is one short (tail padding)
+    cfg = default_config(compat=0, adaptive=1)
+    o = oracle_lib.Oracle(cfg, structure=1)
+    _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z, ic, fr.draws)
+    fin = tmp_path / "frame.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("4i", fr.n, fr.L, len(fr.draws), 0))
+        f.write(fr.types.tobytes()); f.write(fr.ic.astype(np.uint8).tobytes())
+        f.write(fr.x_pred.tobytes()); f.write(np.asfortranarray(fr.P_pred).tobytes(order="F"))
+        f.write(np.ascontiguousarray(fr.z).tobytes()); f.write(fr.draws.tobytes())
+    idfile = tmp_path / "nccl_id"
+    env = dict(os.environ, NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(fin), str(tmp_path / f"out{r}.bin"), str(r), "2", str(idfile), "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank RCCL run on one device hung")
+    if any(p.returncode != 0 for p in procs):
+        text = "\n".join(outs)
+        if "uplicate GPU" in text or "invalid usage" in text.lower() or "ncclCommInitRank" in text:
+            why = [ln for ln in text.splitlines() if "uplicate" in ln or "ncclCommInitRank" in ln or "invalid usage" in ln.lower()]
+            pytest.skip("this RCCL refuses two ranks on one device: " + (why[0].strip()[-200:] if why else "ncclCommInitRank failed"))
+        pytest.fail(text[-2000:])
+    n, L = fr.n, fr.L
+    for r in range(2):
+        raw = open(tmp_path / f"out{r}.bin", "rb").read()
+        sc = np.frombuffer(raw, np.int32, 3); p = 12
+        li = np.frombuffer(raw, np.uint8, L, p); p += L
+        hi = np.frombuffer(raw, np.uint8, L, p); p += L
+        p += L + 16 * L + 32 * L
+        x = np.frombuffer(raw, np.float64, n, p); p += 8 * n
+        P = np.frombuffer(raw, np.float64, n * n, p).reshape(n, n, order="F")
+        assert list(sc) == [r0["best_hyp"], r0["best_support"], r0["hyps_evaluated"]], r
+        assert np.array_equal(li, r0["li"]) and np.array_equal(hi, r0["hi"])
+        assert np.max(np.abs(x - r0["x_new"])) <= 1e-9 * max(1.0, np.abs(r0["x_new"]).max())
+        assert np.max(np.abs(P - r0["P_new"])) <= 1e-9 * np.abs(r0["P_new"]).max()
