@@ -731,7 +731,11 @@ __device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_i
         if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     }
     // (no hardware fence: see cd_post -- the hand-over is LDS only, served in order; the poll's value has been waited for)
+#if defined(CD_HW_FENCES)     // measurement build: the workgroup-scope fences that stood here
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
 }
 
 // Publish: what this wave wrote to LDS, then the flag.  Everything handed over between the waves of the pipeline lives in
@@ -743,7 +747,11 @@ __device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_i
 // operand loads in flight across pivot steps, and each such wait stalled their step, and with it the chain, for a memory latency.
 __device__ __forceinline__ void cd_post(CdShared& sh, int flag, int value)
 {
+#if defined(CD_HW_FENCES)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(&sh.flags[flag], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -2300,7 +2308,7 @@ __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long
 // strips that hold the tiles' rows of Y, then two K = 32 chunks per tile, fetched with sc1 transfers (the strips' stores
 // are write-through: sweep_persistent_kernel, "Memory protocol").  Only the last block's chunks and the epilogue (tile,
 // Jnorm rows / columns, mirrored tile) are left when the pivot chain ends.  Nothing in the sweep waits for a worker.
-constexpr int WK_SLOTS = 3;
+constexpr int WK_SLOTS = 3;          // (2 slots -- no spills at all -- measured no faster: the spilled values are not in the chunk bodies)
 constexpr int WK_TILES = 2 * WK_SLOTS;
 constexpr size_t WK_LDS_BYTES = sizeof(double) * 2 * TD_LDS_DOUBLES;
 static_assert(TD_LDS_DOUBLES >= TS_DOUBLES, "a worker engine's epilogue stages its tile in the operand buffers");
