@@ -814,6 +814,9 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) u[4 * j + k] = Xp[j * 64 + p0 + k];
+                    // (these sixteen values are what lanes p0..p0+3 of THIS wave hold in xp0..xp3; taking them by readlane --
+                    //  32 v_readlane_b32 under the latency of the other reads -- measured 1 us per block SLOWER than the broadcast
+                    //  LDS reads: the chain is bound by the number of instructions this wave issues)
                     __atomic_signal_fence(__ATOMIC_SEQ_CST);
                     if (__all(v >= need)) break;
                     if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
