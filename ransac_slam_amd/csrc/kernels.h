@@ -16,10 +16,25 @@ enum SelSlot {
                              // needs; the host re-runs the update stage with the full-length sequence
     SEL_STATUS_FRONT = 10,   // status of the prediction / scoring stage (kept when only the update stage is re-run)
     SEL_STICKY = 11,         // smallest status of the frames whose status word the next frame's reset has overwritten unread
+    SEL_LI_DEFER = 12,       // != 0: the covariance of the (rank <= 4) low-innovation update has not been written: it is
+                             // P_li = J (sym(P_pred) - Y1 Y1^T) J^T with Y1 (n x 4) and J (Jnorm of that update) kept aside,
+                             // and every reader of P_li until the high-innovation pass has written P forms it on the fly
     SEL_COUNT = 16
 };
 
 constexpr int TG_KC_HOST = 32;   // K granularity of the MFMA tile engine (tile_gemm.h TG_KC)
+
+// The deferred low-innovation covariance (SEL_LI_DEFER): what a reader of P_li needs to form its entries itself.
+// P_li(a, b) = sum J(a, a') M(a', b') J(b, b'),  M = 1/2 (P_pred + P_pred^T) - Y1 Y1^T,  J = I but for rows / columns 3..6,
+// where it is the 4 x 4 Jnorm T1 (column-major) of the low-innovation update (ExtendKF.cpp:608-609,629-634).
+struct DeferArgs {
+    const int32_t* flag;      // sel + SEL_LI_DEFER (nullptr: this launch never reads a deferred covariance)
+    const double* Ppred; long ldp;
+    const double* Y1; long ldy;     // n x 4, zero columns beyond the update's rank
+    const double* T1;
+    double* Gd;               // L x 34: per feature G = H J (2 x 13, rows at 0 and 17) and D = G Y1(cols, :) (2 x 4, at 13 and 30),
+                              // written by the rescue prediction, read by the second P H^T
+};
 
 struct ScoreTables {          // per matched feature (rank j in feature order), m entries each
     const int32_t* feat;      // feature index
@@ -34,7 +49,8 @@ struct ScoreTables {          // per matched feature (rank j in feature order), 
 // h_in / has_h_in: previous prediction (nullable); sel_reset: frame scalars to zero (nullable)
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
                     const uint8_t* type, const int32_t* off, const double* h_in, const uint8_t* has_h_in,
-                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset);
+                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset,
+                    const DeferArgs* defer = nullptr /* P is P_li: possibly deferred (rescue prediction) */);
 
 // out[:, 2c+p] = P[:, cols(list[c])] * H13[list[c]][p]^T for c < count; with wv != nullptr also
 // wv[2c..] = S_f^-1 (z_f - h_f) (K3)
@@ -43,7 +59,7 @@ void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int
                 const uint8_t* type, double* out, long ldo, const double* S, const double* z, const double* h,
                 const uint8_t* has_h, double* wv, int32_t* status,
                 const double* x = nullptr, const int32_t* ith = nullptr, const int32_t* iph = nullptr, double* sc = nullptr /* with wv:
-                the angle table of ScoreTables::sc */);
+                the angle table of ScoreTables::sc */, const DeferArgs* defer = nullptr /* P is P_li: possibly deferred */);
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                   const double* wv, const ScoreTables& tab, const double* z, int m, int words,
@@ -88,6 +104,9 @@ struct WorkerArgs {
     const double* x_in; double* x_out; double* T;          // K9: x_k_k, Jnorm (4 x 4)
     int compat; int token; int32_t* xu_flag;               // token published in *xu_flag when x_k_k and Jnorm are out
     int li_done_slot;                                      // sel[] slot that tells the HI pass whether the LI pass wrote P (mirror tiles equal), -1: never
+    // deferred tiny low-innovation update (SEL_LI_DEFER): the LI launch (token 1) writes Y1 and sets *defer_flag instead of
+    // streaming P; the HI launch (token 2) starts its tiles from P_pred, Y1 and T_li when the flag is up
+    int32_t* defer_flag; double* Y1; long ldy1; const double* Ppred; const double* T_li;
 };
 bool sweep_fused_eligible(const SystemDims& d);            // enough idle compute units for every tile pair of P
 void set_sweep_exp_mask(int mask);     // -1 = environment (RSLAM_SWEEP_EXP); diagnostics and fault injection

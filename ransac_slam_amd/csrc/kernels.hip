@@ -34,12 +34,13 @@ namespace rslam {
 // Two waves per four features: the kernel is ONE instruction stream of ~1900 vector instructions per feature (it runs at
 // 75 waves on 1024 SIMDs: its duration is that stream).  Wave 1 runs the part of the Jacobian that does not need the
 // predicted pixel (jacobian_core, ~860 instructions) while wave 0 runs the prediction (~830) and hands it over through LDS.
+template <bool CAN_DEFER>      // (false: the frame's first prediction -- P is the prior as it stands: none of the deferral code)
 __global__ void __launch_bounds__(128)
 predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ P, int NP, int L,
                const uint8_t* __restrict__ type, const int32_t* __restrict__ off,
                const double* __restrict__ h_in, const uint8_t* __restrict__ has_h_in,   // nullable: no previous h
                double* __restrict__ h, uint8_t* __restrict__ has_h, uint8_t* vis, double* __restrict__ H13,
-               double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */)
+               double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */, DeferArgs da)
 {
     __shared__ double sB[4][26];
     if (sel_reset && blockIdx.x == 0 && threadIdx.x < SEL_COUNT) {   // new frame: the frame scalars start from zero ...
@@ -71,8 +72,27 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
     const int w = is_id ? 13 : 10;
     // lane `sub` owns column jj = sub of (H P): its 13 entries of P are requested first and arrive under the camera model
     double pc[13];
+    // P_li may be deferred (DeferArgs): S = H P_li H^T = G sym(P_pred) G^T - D D^T with G = H J (the Jacobian rows with their
+    // compact columns 3..6 mixed by the low-innovation update's Jnorm) and D = G Y1(cols, :) (2 x 4): the same gather, from
+    // P_pred, a quadratic form with G instead of H (it does not see the asymmetric part of P_pred but in the cross term,
+    // which is averaged below), and a rank-4 correction.  G and D are also what the second P H^T needs per feature: stored.
+    // (the flag is itself a load: nothing below waits for it -- both candidate gathers, Jnorm and the Y1 entries are requested
+    //  at once and arrive under the camera model; the choice is made when they are used)
+    int dflag = 0;
+    if (CAN_DEFER && da.flag) dflag = *da.flag;
 #pragma unroll
     for (int kk = 0; kk < 13; ++kk) pc[kk] = (live && sub < w && kk < w) ? P[col_index(o, kk) + (long)col_index(o, sub) * NP] : 0.0;
+    double pd[13], y1[4] = {0.0, 0.0, 0.0, 0.0}, T1[16];
+    if (CAN_DEFER && da.flag) {
+#pragma unroll
+        for (int kk = 0; kk < 13; ++kk) pd[kk] = (live && sub < w && kk < w) ? da.Ppred[col_index(o, kk) + (long)col_index(o, sub) * da.ldp] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T1[q] = da.T1[q];
+        if (live && sub < w) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y1[c] = da.Y1[col_index(o, sub) + (long)c * da.ldy];
+        }
+    }
     double u = 0, v = 0;
     const bool visible = live && predict_feature(cam, x, o, is_id, u, v);
     const bool had = live && has_h_in && (has_h_in[i] != 0);
@@ -86,6 +106,11 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
     }
     __syncthreads();                         // the other wave's half of the Jacobian is in LDS
     if (!have) return;
+    const bool deferred = CAN_DEFER && dflag != 0;                   // (uniform)
+    if (CAN_DEFER && deferred) {
+#pragma unroll
+        for (int kk = 0; kk < 13; ++kk) pc[kk] = pd[kk];
+    }
     double Bc[26], Hc[26];
 #pragma unroll
     for (int k = 0; k < 26; ++k) Bc[k] = sB[grp][k];
@@ -93,6 +118,36 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
     if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 26; ++k) H13[26 * i + k] = Hc[k];
+    }
+    double d0[4] = {0.0, 0.0, 0.0, 0.0}, d1[4] = {0.0, 0.0, 0.0, 0.0};
+    if (deferred) {
+        // G = H J: G[3+q] = sum_i H[3+i] J(3+i, 3+q) = sum_i H[3+i] T1[i + 4 q]   (T1 column-major)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            double m[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                m[q] = T1[4 * q] * Hc[13 * p + 3] + T1[1 + 4 * q] * Hc[13 * p + 4] + T1[2 + 4 * q] * Hc[13 * p + 5] + T1[3 + 4 * q] * Hc[13 * p + 6];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Hc[13 * p + 3 + q] = m[q];
+        }
+        // D = G Y1(cols, :): lane `sub` contributes its own column, summed over the 16-lane group
+        double g0s = 0.0, g1s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 13; ++kk) if (kk == sub) { g0s = Hc[kk]; g1s = Hc[13 + kk]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { d0[c] = g0s * y1[c]; d1[c] = g1s * y1[c]; }
+#pragma unroll
+        for (int dd = 8; dd >= 1; dd >>= 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { d0[c] += __shfl_xor(d0[c], dd, 16); d1[c] += __shfl_xor(d1[c], dd, 16); }
+        if (sub == 0 && da.Gd) {
+            double* gd = da.Gd + 34L * i;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) { gd[k] = (k < w) ? Hc[k] : 0.0; gd[17 + k] = (k < w) ? Hc[13 + k] : 0.0; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { gd[13 + c] = d0[c]; gd[30 + c] = d1[c]; }
+        }
     }
     double t0 = 0, t1 = 0, hj0 = 0, hj1 = 0;
     if (sub < w) {
@@ -111,6 +166,12 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
         s00 += __shfl_xor(s00, d, 16); s10 += __shfl_xor(s10, d, 16);
         s01 += __shfl_xor(s01, d, 16); s11 += __shfl_xor(s11, d, 16);
     }
+    if (deferred) {
+        const double sx = 0.5 * (s10 + s01);
+        s00 -= (d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3]);
+        s11 -= (d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]);
+        s10 = s01 = sx - ((d0[0] * d1[0] + d0[1] * d1[1]) + (d0[2] * d1[2] + d0[3] * d1[3]));
+    }
     if (sub == 0) {
         S[4 * i + 0] = s00 + radd; S[4 * i + 1] = s10; S[4 * i + 2] = s01; S[4 * i + 3] = s11 + radd;
     }
@@ -118,14 +179,17 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
 
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
                     const uint8_t* type, const int32_t* off, const double* h_in, const uint8_t* has_h_in,
-                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset)
+                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset, const DeferArgs* defer)
 {
+    DeferArgs da{}; if (defer) da = *defer;
     if (L <= 0) {
         if (sel_reset) (void)hipMemsetAsync(sel_reset, 0, sizeof(int32_t) * SEL_COUNT, s);
         return;
     }
-    predict_kernel<<<dim3((L + 3) / 4), dim3(128), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
-                                                        sel_reset);
+    if (defer) predict_kernel<true><<<dim3((L + 3) / 4), dim3(128), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
+                                                                         sel_reset, da);
+    else predict_kernel<false><<<dim3((L + 3) / 4), dim3(128), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
+                                                                     sel_reset, da);
 }
 
 // ---------------------------------------------------------------------------
@@ -141,11 +205,12 @@ struct InnovArgs {            // all nullable together
     const double* x; const int32_t* ith; const int32_t* iph; double* sc;      // angle table of the scoring kernel (nullable)
 };
 
+template <bool CAN_DEFER>
 __global__ void __launch_bounds__(256)
 pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ list, int max_count,
            const int32_t* __restrict__ d_count, const double* __restrict__ H13,
            const int32_t* __restrict__ off, const uint8_t* __restrict__ type, double* __restrict__ out, long ldo,
-           InnovArgs iv)
+           InnovArgs iv, DeferArgs da)
 {
     const int c = blockIdx.y;
     const int count = d_count ? *d_count : max_count;
@@ -175,6 +240,40 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
     const int w = (type[f] == 0) ? 13 : 10;
     double a0 = 0, a1 = 0;
     double pv[13];
+    if (CAN_DEFER && da.flag && *da.flag != 0) {
+        // P is the deferred P_li = J M J^T (DeferArgs): P_li H^T = J (M G^T) with M G^T = P_pred(:, cols) G^T - Y1 D^T; G = H J and
+        // D = G Y1(cols, :) per feature come from the rescue prediction (da.Gd).  P_pred's columns are read as they are (it is
+        // symmetric to rounding: an uploaded prior exactly, one left by rslam_ekf_prediction to ~1e-16 relative; the transposed
+        // entries would be a strided gather per row); the tile workers of the HI pass symmetrise what they write.
+        const double* gd = da.Gd + 34L * f;
+        const bool mix = blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < 7;      // state rows 3..6
+        double t1r[4] = {0.0, 0.0, 0.0, 0.0};
+        if (mix) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t1r[q] = da.T1[(threadIdx.x - 3) + 4 * q];         // (requested with everything else)
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? da.Ppred[row + (long)col_index(o, k) * da.ldp] : 0.0;
+        double y[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) y[cc] = da.Y1[row + (long)cc * da.ldy];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) { a0 += pv[k] * gd[k]; a1 += pv[k] * gd[17 + k]; }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { a0 -= y[cc] * gd[13 + cc]; a1 -= y[cc] * gd[30 + cc]; }
+        // rows 3..6 of the result: J from the left (threads 3..6 of the first row block, one wave)
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            const double p3 = __shfl(a0, 3), p4 = __shfl(a0, 4), p5 = __shfl(a0, 5), p6 = __shfl(a0, 6);
+            const double q3 = __shfl(a1, 3), q4 = __shfl(a1, 4), q5 = __shfl(a1, 5), q6 = __shfl(a1, 6);
+            if (mix) {
+                a0 = t1r[0] * p3 + t1r[1] * p4 + t1r[2] * p5 + t1r[3] * p6;
+                a1 = t1r[0] * q3 + t1r[1] * q4 + t1r[2] * q5 + t1r[3] * q6;
+            }
+        }
+        out[row + (long)(2 * c) * ldo] = a0;
+        out[row + (long)(2 * c + 1) * ldo] = a1;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? P[row + (long)col_index(o, k) * NP] : 0.0;     // all thirteen in flight at once
 #pragma unroll
@@ -188,11 +287,14 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count, const double* H13, const int32_t* off, const uint8_t* type,
                 double* out, long ldo, const double* S, const double* z, const double* h, const uint8_t* has_h,
-                double* wv, int32_t* status, const double* x, const int32_t* ith, const int32_t* iph, double* sc)
+                double* wv, int32_t* status, const double* x, const int32_t* ith, const int32_t* iph, double* sc, const DeferArgs* defer)
 {
     if (max_count <= 0) return;
     InnovArgs iv{S, z, h, has_h, wv, status, x, ith, iph, sc};
-    pht_kernel<<<dim3(NP / 256 + (NP % 256 ? 1 : 0), max_count), dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv);
+    DeferArgs da{}; if (defer) da = *defer;
+    const dim3 grid(NP / 256 + (NP % 256 ? 1 : 0), max_count);
+    if (defer) pht_kernel<true><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da);
+    else pht_kernel<false><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da);
 }
 
 // ---------------------------------------------------------------------------
@@ -515,6 +617,7 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
         sel[SEL_K_LI] = s_running;
         sel[SEL_NBLK_LI] = nblk;
         sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
+        sel[SEL_LI_DEFER] = 0;                       // (an update stage that is re-run starts without a deferred covariance)
         if (nblk > cap_blocks) sel[SEL_CAP_FLAG] = 1;   // launch sequence too short: re-run
     }
 }
@@ -1765,6 +1868,8 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                     const double x0 = q0 / l00, x1 = (q1 - x0 * l10) / l11, x2 = (q2 - x0 * l20 - x1 * l21) / l22,
                                  x3 = (q3 - x0 * l30 - x1 * l31 - x2 * l32) / l33;
                     acc[0][0] = lq == 0 ? x0 : lq == 1 ? x1 : lq == 2 ? x2 : x3;
+                    // (low-innovation pass: Y1 kept aside for the deferred covariance, SEL_LI_DEFER)
+                    if (xrows && wk.token == 1 && wk.Y1) wk.Y1[first_row + ln + (long)lq * wk.ldy1] = acc[0][0];
                     if (xrows) {
                         // K9 here: u^T = nu^T L^-T by the same substitution on the innovation row (every strip for itself: no hop)
                         double nu4[4];
@@ -2332,6 +2437,101 @@ __device__ __forceinline__ WkTile wk_tile(const WorkerArgs& wk, int ti, int ntil
     return r;
 }
 
+// K11 on one tile of the first block column, in its LDS image Cs[col][row] (64 threads, j = row of tile (bi,0) = column of
+// its mirror): the Jnorm congruence on rows / columns 3..6 (ExtendKF.cpp:629-634); same arithmetic as a separate pass over
+// P would do.  For bi != 0 only the tile's columns 3..6 change (its mirror carries the rows).
+__device__ __forceinline__ void wk_jnorm_tile(double* Cs, const double (&T)[16], int bi, int j)
+{
+    if (bi != 0) {
+        double rb[4];
+        for (int i = 0; i < 4; ++i) {
+            double sacc = 0;
+            for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[(3 + q) * TS_LD + j];   // P(3+q, col) by symmetry
+            rb[i] = sacc;
+        }
+        for (int i = 0; i < 4; ++i) Cs[(3 + i) * TS_LD + j] = rb[i];
+    } else if (!(j >= 3 && j < 7)) {
+        double rb[4];
+        for (int i = 0; i < 4; ++i) {
+            double sacc = 0;
+            for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[j * TS_LD + (3 + q)];
+            rb[i] = sacc;
+        }
+        for (int i = 0; i < 4; ++i) { Cs[j * TS_LD + (3 + i)] = rb[i]; Cs[(3 + i) * TS_LD + j] = rb[i]; }
+    } else if (j == 3) {
+        double cb[4][4], out[4][4];         // cb = J * P44 ; out = cb * J^T
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 4; ++c) {
+                double sacc = 0;
+                for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[(3 + c) * TS_LD + (3 + q)];
+                cb[i][c] = sacc;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 4; ++c) {
+                double sacc = 0;
+                for (int q = 0; q < 4; ++q) sacc += cb[i][q] * T[c + 4 * q];
+                out[i][c] = sacc;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = out[i][c];
+    }
+}
+
+// The high-innovation pass found no inliers and the low-innovation covariance was deferred: P_li is written now, by every
+// workgroup of the launch (one tile pair at a time per four waves, through LDS): J (sym(P_pred) - Y1 Y1^T) J^T.
+__device__ __forceinline__ void wk_materialise_deferred(const WorkerArgs& wk, int NP, double* lds)
+{
+    const int ntiles = wk.nT * (wk.nT + 1) / 2;
+    const int t = threadIdx.x, half = t >> 8, t4 = t & 255, row = t4 & 63, g4 = t4 >> 6;
+    for (int i = (int)(blockIdx.x * blockDim.x) + t; i < NP; i += (int)(gridDim.x * blockDim.x)) wk.x_out[i] = wk.x_in[i];
+    double T1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T1[q] = wk.T_li[q];
+    double* Cs = lds + (size_t)half * TD_LDS_DOUBLES;
+    double* Ts = Cs + TS_DOUBLES;
+    for (int base = 2 * (int)blockIdx.x; base < ntiles; base += 2 * (int)gridDim.x) {      // (uniform trip count: barriers inside)
+        const WkTile tl = wk_tile(wk, base + half, ntiles);
+        const double* Pij = wk.Ppred + 64L * tl.bi + 64L * tl.bj * wk.ldp;
+        const double* Pji = wk.Ppred + 64L * tl.bj + 64L * tl.bi * wk.ldp;
+        if (tl.have) {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int c = g4 + 4 * q;
+                Cs[c * TS_LD + row] = Pij[row + (long)c * wk.ldp];
+                Ts[c * TS_LD + row] = Pji[row + (long)c * wk.ldp];
+            }
+        }
+        __syncthreads();
+        if (tl.have) {
+            double yr[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) yr[c] = wk.Y1[64L * tl.bi + row + (long)c * wk.ldy1];
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int c = g4 + 4 * q;
+                double v = 0.5 * Cs[c * TS_LD + row] + 0.5 * Ts[row * TS_LD + c];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v -= yr[cc] * wk.Y1[64L * tl.bj + c + (long)cc * wk.ldy1];
+                Cs[c * TS_LD + row] = v;           // (each thread rewrites exactly the entries it read from Cs)
+            }
+        }
+        __syncthreads();
+        if (tl.have && tl.bj == 0 && t4 < 64) wk_jnorm_tile(Cs, T1, tl.bi, t4);
+        __syncthreads();
+        if (tl.have) {
+            double* Cij = wk.Pout + 64L * tl.bi + 64L * tl.bj * wk.ldo;
+            double* Cji = wk.Pout + 64L * tl.bj + 64L * tl.bi * wk.ldo;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int c = g4 + 4 * q;
+                Cij[row + (long)c * wk.ldo] = Cs[c * TS_LD + row];
+                if (tl.bi != tl.bj) Cji[row + (long)c * wk.ldo] = Cs[row * TS_LD + c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // update() pass-through (no inliers, ExtendKF.cpp:635-638): every workgroup of the launch copies its share
 __device__ __forceinline__ void wk_passthrough(const WorkerArgs& wk, int NP)
 {
@@ -2412,7 +2612,10 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
     // ---- accumulators = 1/2 (P + P^T) of the tile, in the MFMA result layout (tg_acc_to_lds).  The HI pass reads what the
     // LI pass wrote -- mirrored pairs, exactly symmetric off the diagonal tiles -- so there the mirror tile need not be read
     // and the tile comes straight from memory (128-byte row segments, under the wait for the first column block).
-    const bool li_wrote = wk.li_done_slot >= 0 && sel[wk.li_done_slot] > 0;
+    // (high-innovation pass behind a deferred low-innovation update: the tiles start from P_pred, Y1 and that update's Jnorm)
+    const bool deferred = wk.token == 2 && wk.defer_flag && *wk.defer_flag != 0;
+    const double* Pin = deferred ? wk.Ppred : wk.Pin;
+    const bool li_wrote = !deferred && wk.li_done_slot >= 0 && sel[wk.li_done_slot] > 0;
     const bool staged = !li_wrote && nblk == 1;
     TgAcc acc[WK_SLOTS];
     double* hbase = lds + (size_t)half * TD_LDS_DOUBLES;
@@ -2424,8 +2627,8 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
 #pragma unroll
         for (int slot = 0; slot < WK_SLOTS; ++slot) {
             tg_zero(acc[slot]);
-            const double* Pij = wk.Pin + 64L * tl[slot].bi + 64L * tl[slot].bj * wk.ldp;
-            const double* Pji = wk.Pin + 64L * tl[slot].bj + 64L * tl[slot].bi * wk.ldp;
+            const double* Pij = Pin + 64L * tl[slot].bi + 64L * tl[slot].bj * wk.ldp;
+            const double* Pji = Pin + 64L * tl[slot].bj + 64L * tl[slot].bi * wk.ldp;
             if (staged) {
                 // both tiles of the pair, each in 512-byte column runs, through LDS (the mirror tile is needed transposed):
                 // a system of one diagonal block is done in microseconds, the pass is then a stream over P and this read is
@@ -2471,6 +2674,56 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
                     acc[slot][mi][0][q] = mirror_known ? pij : 0.5 * pij + 0.5 * Pji[col + (long)row * wk.ldp];
                 }
         }
+    }
+    if (deferred) {
+        // M = sym(P_pred) - Y1 Y1^T entry by entry (rank <= 4: VALU), then the low-innovation update's Jnorm congruence on the
+        // tiles of the first block column, through LDS as in the epilogue (uniform barriers: both engines take them)
+        const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+        double T1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T1[q] = wk.T_li[q];
+        double* Cs = hbase;
+        const int t4 = t & 255;
+        static_for<0, WK_SLOTS>([&](auto S) {
+            constexpr int slot = decltype(S)::value;
+            if (slot < n_wg) {
+                const bool mine = tl[slot].have;
+                if (mine) {
+                    double yc[4][4];                              // Y1 rows of this lane's four columns
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            yc[q][c] = wk.Y1[64L * tl[slot].bj + wave4 * 16 + 4 * ((blk - q) & 3) + j + (long)c * wk.ldy1];
+#pragma unroll
+                    for (int mi = 0; mi < TG_MI; ++mi) {
+                        double yr[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) yr[c] = wk.Y1[64L * tl[slot].bi + mi * 16 + 4 * blk + i + (long)c * wk.ldy1];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[slot][mi][0][q] -= ((yr[0] * yc[q][0] + yr[1] * yc[q][1]) + yr[2] * yc[q][2]) + yr[3] * yc[q][3];
+                    }
+                }
+                const WkTile t0 = wk_tile(wk, widx + (2 * slot) * W, ntiles), t1 = wk_tile(wk, widx + (2 * slot + 1) * W, ntiles);
+                if ((t0.have && t0.bj == 0) || (t1.have && t1.bj == 0)) {            // (uniform over the workgroup)
+                    const bool fix = mine && tl[slot].bj == 0;
+                    __syncthreads();
+                    if (fix) tg_acc_to_lds_w(acc[slot], Cs, 1.0, wave4);
+                    __syncthreads();
+                    if (fix && t4 < 64) wk_jnorm_tile(Cs, T1, tl[slot].bi, t4);
+                    __syncthreads();
+                    if (fix) {
+#pragma unroll
+                        for (int mi = 0; mi < TG_MI; ++mi)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[slot][mi][0][q] = Cs[(wave4 * 16 + 4 * ((blk - q) & 3) + j) * TS_LD + mi * 16 + 4 * blk + i];
+                    }
+                }
+            }
+        });
+        __syncthreads();
     }
     // ---- the strips whose flag words this workgroup polls: lane = (tile, operand, strip of the 64-row block)
     int my_flag = -1;
@@ -2525,40 +2778,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
                 double T[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) T[q] = ld_coh(wk.T + q);
-                const int j = t4;
-                if (bi != 0) {
-                    double rb[4];
-                    for (int i = 0; i < 4; ++i) {
-                        double sacc = 0;
-                        for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[(3 + q) * TS_LD + j];   // P(3+q, col) by symmetry
-                        rb[i] = sacc;
-                    }
-                    for (int i = 0; i < 4; ++i) Cs[(3 + i) * TS_LD + j] = rb[i];
-                } else if (!(j >= 3 && j < 7)) {
-                    double rb[4];
-                    for (int i = 0; i < 4; ++i) {
-                        double sacc = 0;
-                        for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[j * TS_LD + (3 + q)];
-                        rb[i] = sacc;
-                    }
-                    for (int i = 0; i < 4; ++i) { Cs[j * TS_LD + (3 + i)] = rb[i]; Cs[(3 + i) * TS_LD + j] = rb[i]; }
-                } else if (j == 3) {
-                    double cb[4][4], out[4][4];         // cb = J * P44 ; out = cb * J^T
-                    for (int i = 0; i < 4; ++i)
-                        for (int c = 0; c < 4; ++c) {
-                            double sacc = 0;
-                            for (int q = 0; q < 4; ++q) sacc += T[i + 4 * q] * Cs[(3 + c) * TS_LD + (3 + q)];
-                            cb[i][c] = sacc;
-                        }
-                    for (int i = 0; i < 4; ++i)
-                        for (int c = 0; c < 4; ++c) {
-                            double sacc = 0;
-                            for (int q = 0; q < 4; ++q) sacc += cb[i][q] * T[c + 4 * q];
-                            out[i][c] = sacc;
-                        }
-                    for (int i = 0; i < 4; ++i)
-                        for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = out[i][c];
-                }
+                wk_jnorm_tile(Cs, T, bi, t4);
             }
             __syncthreads();
             if (mine) {
@@ -2603,14 +2823,23 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
     int nblk = sel[slot_nblk];
     if (nblk > rp_blocks) nblk = rp_blocks;
     if (nblk <= 0) {                                          // no inliers: update() is the identity (ExtendKF.cpp:635-638)
-        if (fused) wk_passthrough(wk, NP);
+        if (fused) {
+            if (wk.token == 2 && wk.defer_flag && *wk.defer_flag != 0) wk_materialise_deferred(wk, NP, lds);   // ... of P_li, which does not exist yet
+            else wk_passthrough(wk, NP);
+        }
         return;
     }
     const int r_total = 2 * sel[slot_k];
     const bool single = (nblk == 1) && !(exp_mask & 4);       // one diagonal block: every strip factors it itself, no chain workgroup
     const int nstrips = (int)(ldA / 16);
     const int bx = (int)blockIdx.x;
+    // A low-innovation update of rank <= 4 (the reference-faithful mode: the consensus set is the hypothesis' own feature) is
+    // four microseconds of strip work and then one stream over P for a rank-2 correction.  That stream is DEFERRED: the
+    // strips keep Y1 aside, the flag goes up, and until the high-innovation pass writes P every reader of P_li forms it
+    // from P_pred, Y1 and this update's Jnorm (DeferArgs; rescue prediction, second P H^T, the HI pass's tile workers).
+    const bool li_defer = fused && wk.token == 1 && wk.defer_flag && wk.Y1 && single && r_total <= 4 && !(exp_mask & (8 | 512));
     if (bx == 0) {
+        if (li_defer && threadIdx.x == 0) *wk.defer_flag = 1;
         if (single) return;
         // (exp_mask & 16: fault injection for tests/test_gpu_parity.py -- the chain workgroup never shows up, as if it had not
         //  been scheduled: every strip must run into its bounded wait and the host must recover the frame)
@@ -2635,7 +2864,7 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
         const int n_late = single ? NP / 16 + 1 : 0;
         const int n_workers = extra + n_idle_s + 3 + n_late;
         if (widx >= 0) {
-            sweep_tile_worker(widx, n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg, exp_mask);
+            if (!li_defer) sweep_tile_worker(widx, n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg, exp_mask);
             return;
         }
         if (single && bx <= nstrips) {
@@ -2644,6 +2873,7 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
             const int strip = bx - 1;
             sweep_strip<NJ>(A, ldA, rp_blocks, nblk, strip, r_total, NP, src, Linv, Ypanel, fl, status, lds, dbg, single, sel, slot_k,
                             (exp_mask & 8) != 0, wk, exp_mask);
+            if (li_defer) return;
             __syncthreads();                                  // the strip's LDS is free
             sweep_tile_worker(extra + n_idle_s + 3 + (strip - 4 * rp_blocks), n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k,
                               status, lds, &s_wk_abort, nullptr, exp_mask);
@@ -2716,7 +2946,8 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_TOTAL, nullable = only (un
 // shared route too, bit 3 no register-only route for systems of <= 4 rows, bit 4 fault injection (the chain
 // workgroup does not run), bit 5 fault injection (the strips never announce their Y blocks: tile workers and the x update
 // run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep), bit 8 the time
-// stamps of scripts/sweep_stamps.py come from the LI pass instead of the HI pass;
+// stamps of scripts/sweep_stamps.py come from the LI pass instead of the HI pass, bit 9 a low-innovation update of rank <= 4
+// streams P at once instead of deferring its covariance to the high-innovation pass;
 // set_sweep_exp_mask overrides the environment (tests)
 static int g_sweep_exp_override = -1;
 void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }

@@ -74,7 +74,7 @@ struct rslam_ctx {
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Y, d_Linv,
-                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr, d_sc;
+                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr, d_sc, d_Y1, d_Gd;
     DevBuf<uint8_t> d_image;
     // feature store: initialisation records of Map::initialize_a_features (Map.cpp:286-292), one slot per feature
     DevBuf<double> d_rec;                 // slot * 14: uv(2) R(9 col-major) r(3)
@@ -218,7 +218,7 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->ev_ok = (n_ev == EV_COUNT);
     if (!c->ev_ok) for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     memset(&c->times, 0, sizeof(c->times));
-    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(16) < 0 || c->d_sweep_flags.ensure(2 * SWEEP_FLAG_INTS) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
+    if (c->d_sel.ensure(SEL_COUNT) < 0 || c->d_T.ensure(32) < 0 || c->d_sweep_flags.ensure(2 * SWEEP_FLAG_INTS) < 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     if (hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_sel.p, 0, sizeof(int32_t) * SEL_COUNT, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
@@ -244,7 +244,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
     c->d_sup_local.release(); c->d_sup_all.release();
-    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_sc.release();
+    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
@@ -293,7 +293,7 @@ static int set_layout(rslam_ctx* c, const rslam_layout* lay)
 #define ENS(buf, cnt) do { r = (buf).ensure(cnt); if (r < 0) return RSLAM_ERR_HIP; re |= r; } while (0)
     ENS(c->d_type, L); ENS(c->d_off, L); ENS(c->d_vis, L); ENS(c->d_hash, L); ENS(c->d_hash2, L);
     ENS(c->d_ic, L); ENS(c->d_li, L); ENS(c->d_hi, L); ENS(c->d_rank_of, L);
-    ENS(c->d_xpred, NP); ENS(c->d_x1, NP); ENS(c->d_x2, NP); ENS(c->d_FQ, 338);
+    ENS(c->d_xpred, NP); ENS(c->d_x1, NP); ENS(c->d_x2, NP); ENS(c->d_FQ, 338); ENS(c->d_Y1, 4 * (size_t)NP); ENS(c->d_Gd, 34 * (size_t)L);
     ENS(c->d_Ppred, (size_t)NP * NP); ENS(c->d_P, (size_t)NP * NP);
     ENS(c->d_h, 2 * (size_t)L); ENS(c->d_h2, 2 * (size_t)L); ENS(c->d_H13, 26 * (size_t)L); ENS(c->d_H13b, 26 * (size_t)L);
     ENS(c->d_S, 4 * (size_t)L); ENS(c->d_S2, 4 * (size_t)L); ENS(c->d_z, 2 * (size_t)L);
@@ -519,6 +519,9 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         wk.token = (slot_k == SEL_K_LI) ? 1 : 2;          // sel[] is zeroed at the start of a frame (predict_kernel)
         wk.xu_flag = sel + SEL_XU_FLAG;
         wk.li_done_slot = (slot_k == SEL_K_HI) ? SEL_NBLK_LI : -1;
+        // Jnorm of the LI update at d_T, of the HI update behind it: the HI pass may still need the LI one (deferred covariance)
+        wk.T = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
+        wk.defer_flag = sel + SEL_LI_DEFER; wk.Y1 = c->d_Y1.p; wk.ldy1 = c->NP; wk.Ppred = c->d_Ppred.p; wk.T_li = c->d_T.p;
     }
     {
         static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // two-stream variant, measured slower: off
@@ -588,9 +591,12 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     if (rc) return rc;
     mark(c, EV_LI_END);
     // rescue (Tracking.cpp:574-597): re-predict at x_k_k; invisible features keep their stale h
+    // (P_li may be deferred -- a rank <= 4 low-innovation update keeps Y1 and its Jnorm aside instead of streaming P: the readers
+    //  of P_li between here and the HI pass form its entries themselves, kernels.h DeferArgs)
+    DeferArgs da{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p, c->d_Gd.p};
     launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
                    c->d_h2.p, c->d_hash2.p, nullptr, c->d_H13b.p, c->d_S2.p,
-                   c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr);
+                   c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr, &da);
     launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
                        cap_hi, c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
@@ -603,7 +609,7 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
     if (c->RP > 0)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
-                   c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                   c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &da);
     rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, cap_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;

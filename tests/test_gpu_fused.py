@@ -194,3 +194,46 @@ def test_status_of_an_unsynced_frame_is_not_lost(hip):
     g.step_frame(False)
     g.sync()                                              # reported once: the context is clean again
     g.close()
+
+
+@pytest.mark.parametrize("L,H,seed", [(90, 120, 21), (300, 200, 2), (40, 100, 7)])
+def test_deferred_li_covariance_equals_immediate(hip, oracle_lib, L, H, seed):
+    """A low-innovation update of rank <= 4 (compat = 1: the consensus set is the hypothesis' own feature) does not stream P:
+    Y1 and its Jnorm are kept aside and the rescue prediction, the second P H^T and the HI pass's tile workers form
+    P_li = J (sym(P_pred) - Y1 Y1^T) J^T themselves (SEL_LI_DEFER).  Same frame with the deferral (default), with the
+    immediate stream (RSLAM_SWEEP_EXP bit 9) and with the stand-alone rank update (bit 7): all against the oracle, and
+    the decisions of the rescue gate (which sees the deferred S) identical."""
+    fr = make_frame(L=L, H=H, seed=seed)
+    cfg = default_config(compat=1, adaptive=0)
+    ic, r0 = oracle_frame(oracle_lib, fr, cfg)
+    assert int(r0["li"].sum()) in (1, 2)
+    out = {}
+    for mask in (0, 512, 128):
+        hip.lib().rslam_debug_set_sweep_exp(mask)
+        try:
+            g = hip.RslamHip(cfg)
+            g.predict(fr.types, fr.x_pred, fr.P_pred)
+            out[mask] = g.ransac_update(fr.z, ic, fr.draws)
+            g.close()
+        finally:
+            hip.lib().rslam_debug_set_sweep_exp(-1)
+        r1 = out[mask]
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"]), mask
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"]), mask
+    assert close_P(out[0]["P_new"], out[512]["P_new"], 1e-11) and close_x(out[0]["x_new"], out[512]["x_new"], 1e-12)
+
+
+def test_deferred_li_covariance_without_hi_inliers(hip, oracle_lib):
+    """... and when the rescue gate lets nobody through (chi-square gate at ~0) the high-innovation pass is a pass-through of
+    a covariance that does not exist yet: it has to be written then (wk_materialise_deferred)."""
+    fr = make_frame(L=90, H=120, seed=21)
+    cfg = default_config(compat=1, adaptive=0)
+    cfg.chi2_gate = 1e-12
+    ic, r0 = oracle_frame(oracle_lib, fr, cfg)
+    assert int(r0["li"].sum()) >= 1 and int(r0["hi"].sum()) == 0
+    g = hip.RslamHip(cfg)
+    g.predict(fr.types, fr.x_pred, fr.P_pred)
+    r1 = g.ransac_update(fr.z, ic, fr.draws)
+    g.close()
+    assert np.array_equal(r1["li"], r0["li"]) and not r1["hi"].any()
+    assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
