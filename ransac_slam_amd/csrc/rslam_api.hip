@@ -637,6 +637,15 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     // resets into SEL_STICKY): reported with this frame, then cleared
     int sticky = sel[SEL_STICKY];
     if (sticky != 0) HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STICKY, 0, sizeof(int32_t), c->stream));
+    if (sticky <= -30 && sticky != -39) {
+        // An earlier frame of this unsynchronised run hit a bounded wait of the persistent sweep (somebody else held compute
+        // units).  Nobody used its posterior -- every consumer settles the frame in flight first -- so it is not an error of
+        // this call; but the environment is hostile: take the launch-per-step path for a while, as for a timeout seen directly.
+        c->last_raw_status = sticky;
+        ++c->sweep_fallbacks;
+        if (c->steps_frames_left == 0) { c->steps_frames_left = 64 << (c->consecutive_fallbacks < 6 ? c->consecutive_fallbacks : 6); ++c->consecutive_fallbacks; invalidate_graph(c); }
+        sticky = 0;
+    }
     if (c->frame_checked) {
         // this frame has been reported before: its status words were taken off the device then (so that the next frame's
         // reset does not report them a second time) and are remembered here
