@@ -47,9 +47,9 @@ def pmc_traffic_bytes(kernel_substr):
     gfx950 (MI355X_MICROARCH.md, HBM section; confirmed on pht_kernel).  'max' = the large (HI) pass."""
     import csv
     try:
-        # (a summary older than the kernels it describes would be a stale figure: not reported then)
-        src = [os.path.join(ROOT, "ransac_slam_amd", "csrc", f) for f in ("kernels.hip", "tile_gemm.h")]
-        if os.path.getmtime(PMC_SUMMARY) < max(os.path.getmtime(f) for f in src) - 1.0:
+        # (a summary of other kernel sources than the ones in the tree would be a stale figure: not reported then;
+        #  scripts/collect_profiles.sh writes the digest next to the summary)
+        if open(PMC_SUMMARY[:-4] + ".src_sha256").read().split()[0] != kernel_sources_digest():
             return None
         rows = [r for r in csv.DictReader(open(PMC_SUMMARY)) if kernel_substr in r["kernel"]]
         fetch = max(float(r["max"]) for r in rows if r["counter"] == "FETCH_SIZE")
@@ -57,6 +57,15 @@ def pmc_traffic_bytes(kernel_substr):
         return (2.0 * fetch + write) * 1024.0
     except Exception:
         return None
+
+
+def kernel_sources_digest():
+    """sha256 over the sources of the kernels the PMC summary describes"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "tile_gemm.h", "kernels.h", "camera_model.h"):
+        h.update(open(os.path.join(ROOT, "ransac_slam_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def cpu_model():

@@ -119,7 +119,7 @@ struct SysSrc {
     const double* z; const double* h; const double* Wsrc; const int32_t* rank_of;
 };   // the whole sweep in one launch (no dependence on the previous frame's counts)
 // returns the buffer (A or Ystore, same shape) whose rows [RP, RP + NP] hold Y and u^T afterwards
-double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev, const SystemDims& d, const int32_t* sel,
+double* launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel,
                             int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
                             int32_t* status_sel, int32_t* flags /* 2 * SWEEP_FLAG_INTS zeroed ints, or nullptr: never the persistent sweep */,
                             const SysSrc* src /* with flags: the sweep assembles the system itself (no launch_prepare_system) */,

@@ -1402,14 +1402,6 @@ __device__ __forceinline__ void trail_tile(double* __restrict__ A, long ldA, int
     }
 }
 
-__global__ void __launch_bounds__(256)
-trail_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-             int rp_blocks, int skip_next_diag)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    trail_tile(A, ldA, step, sel[slot_nblk], rp_blocks, blockIdx.x, blockIdx.y + step + 1, skip_next_diag, lds);
-}
-
 // One launch per block step k of the sweep:
 //   workgroup 0      forms its own panel row X = A(k+1,k) Linv(k)^T, applies the step-k update to tile
 //                    (k+1,k+1) and factors it (cd_factor_block, pending = 2): the serial chain of the sweep;
@@ -2418,7 +2410,6 @@ __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long
 // Jnorm rows / columns, mirrored tile) are left when the pivot chain ends.  Nothing in the sweep waits for a worker.
 constexpr int WK_SLOTS = 3;          // (2 slots -- no spills at all -- measured no faster: the spilled values are not in the chunk bodies)
 constexpr int WK_TILES = 2 * WK_SLOTS;
-constexpr size_t WK_LDS_BYTES = sizeof(double) * 2 * TD_LDS_DOUBLES;
 static_assert(TD_LDS_DOUBLES >= TS_DOUBLES, "a worker engine's epilogue stages its tile in the operand buffers");
 
 struct WkTile { int bi, bj; bool have; };
@@ -2907,8 +2898,6 @@ int init_kernel_attributes()
     hipError_t e = hipSuccess;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
@@ -2988,13 +2977,11 @@ bool sweep_fused_eligible(const SystemDims& d)
 
 // One stream: diag(0), then ONE launch per block step (sweep_step_kernel); for large systems (more than 512 tile
 // workgroups at the first step) panel(k) + trail_diag(k) instead, see trail_diag_kernel.
-// RSLAM_SWEEP_UNFUSED=1 selects the three-kernels-per-step sequence (diag(k) panel(k) trail(k)) for
-// measurement.  A two-stream lookahead variant (aux != nullptr) is kept for measurement only:
-// on MI355X / ROCm 7.2 the cross-stream event dependencies cost more than the trailing kernels
-// they hide (C3 frame 0.68 ms against 0.52 ms single-stream, eager and hipGraph alike).
+// (A two-stream lookahead variant and a three-kernels-per-step sequence existed in rounds 1-2 for measurement: the cross-stream
+// event dependencies cost more than the trailing kernels they hide -- C3 frame 0.68 ms against 0.52 ms single-stream.)
 // Returns the buffer whose rows [RP, RP + NP] hold Y and u^T afterwards: Ystore for the one-launch-per-step
 // sequence, A itself for the others.
-double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 * rp_blocks */, const SystemDims& d,
+double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
                             const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
                             int32_t* status_sel, int32_t* flags, const SysSrc* src, const WorkerArgs* wk)
 {
@@ -3002,9 +2989,7 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
     const int steps = cap_blocks < rp_blocks ? cap_blocks : rp_blocks;
     const int row_blocks = d.ldA / 64;
     const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
-    const bool two = (aux != nullptr && ev != nullptr);
-    static const bool unfused = getenv("RSLAM_SWEEP_UNFUSED") != nullptr;
-    if (!two && !unfused && flags && src && sweep_persistent_eligible(d)) {
+    if (flags && src && sweep_persistent_eligible(d)) {
         // one launch for the whole sweep, sized for the largest inlier count the frame can have: the launch sequence
         // never depends on the previous frame (cap_blocks is not used)
         WorkerArgs wa{};                                   // Pout == nullptr: the caller launches the rank update itself
@@ -3024,7 +3009,7 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
 #undef SWP_LAUNCH
         return Ystore;
     }
-    if (!two && !unfused && (long)row_blocks * steps > 512) {
+    if ((long)row_blocks * steps > 512) {
         // large system: panel once per step, then trailing update + next diagonal block in one launch
         if (steps <= 0) return A;
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
@@ -3036,31 +3021,12 @@ double* launch_factor_sweep(hipStream_t s, hipStream_t aux, hipEvent_t* ev /* 2 
         }
         return A;
     }
-    if (!two && !unfused) {
-        if (steps <= 0) return Ystore;
-        chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
-        for (int step = 0; step < steps; ++step)     // column jj = 0 also stores the panel, so the last step still has one
-            sweep_step_kernel<<<dim3(1 + row_blocks * (steps - step)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
-                A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel);
-        return Ystore;
-    }
-    for (int step = 0; step < steps; ++step) {
-        chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, step, sel, slot_nblk, slot_k, Linv, status_sel, (two && step > 0) ? 1 : 0);
-        if (two && step > 0) (void)hipStreamWaitEvent(s, ev[2 * (step - 1) + 1], 0);      // trail(step-1) done
-        panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
-        if (step + 1 < steps) {
-            hipStream_t ts = s;
-            if (two) {
-                (void)hipEventRecord(ev[2 * step], s);
-                (void)hipStreamWaitEvent(aux, ev[2 * step], 0);
-                ts = aux;
-            }
-            trail_kernel<<<dim3(row_blocks, steps - step - 1), dim3(256), lds_bytes, ts>>>(A, d.ldA, step, sel, slot_nblk, rp_blocks, two ? 1 : 0);
-            if (two) (void)hipEventRecord(ev[2 * step + 1], aux);
-        }
-    }
-    // the last trail(steps-2) was joined before panel(steps-1): nothing is left on aux
-    return A;
+    if (steps <= 0) return Ystore;
+    chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
+    for (int step = 0; step < steps; ++step)     // column jj = 0 also stores the panel, so the last step still has one
+        sweep_step_kernel<<<dim3(1 + row_blocks * (steps - step)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
+            A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel);
+    return Ystore;
 }
 
 // ---------------------------------------------------------------------------

@@ -57,8 +57,6 @@ struct rslam_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t aux_stream = nullptr;            // trailing updates of the factor sweep (lookahead)
-    std::vector<hipEvent_t> sweep_ev;            // fork/join events, 2 per block step
     // frame shape
     int n = 0, NP = 0, L = 0, m = 0, H = 0, words = 0, RP = 0, ldA = 0;
     int m_id = 0, m_euc = 0;
@@ -211,7 +209,6 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     // every failure path below goes through rslam_destroy, which releases whatever exists so far
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->own_stream = nullptr; (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
     if (init_kernel_attributes() != 0 || init_kernel_attributes2() != 0) { (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     int n_ev = 0;
     for (; n_ev < EV_COUNT; ++n_ev) if (hipEventCreate(&c->ev[n_ev]) != hipSuccess) break;
@@ -247,8 +244,6 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
-    for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RSLAM_OK;
@@ -523,19 +518,8 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         wk.T = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
         wk.defer_flag = sel + SEL_LI_DEFER; wk.Y1 = c->d_Y1.p; wk.ldy1 = c->NP; wk.Ppred = c->d_Ppred.p; wk.T_li = c->d_T.p;
     }
-    {
-        static const bool want_lookahead = getenv("RSLAM_SWEEP_LOOKAHEAD") != nullptr;   // two-stream variant, measured slower: off
-        const size_t need = 2 * (size_t)(c->RP / 64 + 1);
-        while (want_lookahead && c->sweep_ev.size() < need) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
-            c->sweep_ev.push_back(e);
-        }
-        const bool two = want_lookahead && c->aux_stream && c->sweep_ev.size() >= need;
-        Ysys = launch_factor_sweep(s, two ? c->aux_stream : nullptr, two ? c->sweep_ev.data() : nullptr, d, sel, slot_k, slot_nblk,
-                                   cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
-                                   persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr, fused ? &wk : nullptr);
-    }
+    Ysys = launch_factor_sweep(s, d, sel, slot_k, slot_nblk, cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
+                               persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr, fused ? &wk : nullptr);
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP <= 0) HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
     if (ev_r0 >= 0) mark(c, ev_r0);
@@ -625,14 +609,13 @@ static int read_status_raw(rslam_ctx* c, int32_t* sel)
     return RSLAM_OK;
 }
 
-// Synchronise, handle a sweep-cap overflow by re-running the update stage at full length,
-// adapt the caps for the next frame, return the device-side status of the frame.
+// Synchronise and return the device-side status of the frame (and of earlier frames nobody synchronised on); a bounded
+// wait that ran out inside a persistent launch is handled here: re-run from the kept inputs, launch-per-step for a while.
 static int read_status(rslam_ctx* c, int32_t* sel_host)
 {
     int32_t sel[SEL_COUNT];
     int rc = read_status_raw(c, sel);
     if (rc) return rc;
-    const int rp_blocks = c->RP / 64;
     // statuses of frames that were enqueued behind each other without a sync in between (predict_kernel folds the word it
     // resets into SEL_STICKY): reported with this frame, then cleared
     int sticky = sel[SEL_STICKY];

@@ -21,6 +21,7 @@ cd "$root"
 stats=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
 cp "$stats" "$out/kernel_stats.csv"
 python3 scripts/pmc_summary.py "$out/pmc_summary.csv" "$out"/pmc_fetch/* "$out"/pmc_write/* "$out"/pmc_mfma/* "$out"/pmc_valu/* 2>&1 | tail -2
+python3 -c "import sys; sys.path.insert(0, '$root'); import bench; print(bench.kernel_sources_digest())" > "$out/pmc_summary.src_sha256"
 # keep the merge-back small: the raw traces stay on the box
 rm -rf "$out/trace" "$out"/pmc_fetch "$out"/pmc_write "$out"/pmc_mfma "$out"/pmc_valu
 ls -la "$out"
