@@ -1515,6 +1515,216 @@ trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
     trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
 }
 
+// The trailing update as a stream (what large systems run).  The tiles of a pass, row-major over the active rows, are dealt
+// out in contiguous ranges to at most (compute units - 1) workgroups, and the two four-wave engines of a workgroup take
+// alternate tiles of its range: two tiles in flight per compute unit instead of one (trail_diag_kernel retires half of its
+// waves and, with the diagonal block's LDS, runs one workgroup per compute unit: 2.7 TB/s of tile traffic at C5), no
+// workgroup launch / drain per tile, operands through the LDS-DMA engine of the rank update.  HBM-bound (64 KB per tile and
+// pass), so a pass applies TWO panels wherever the dependencies allow (launch_factor_sweep: block steps in pairs):
+//   narrow pass (NPAN = 1, one_col): panel k onto column block j_lo = k + 1 only -- and onto the diagonal tile after it
+//                (`extra`), which the NEXT diagonal workgroup needs complete but for its own panel;
+//   wide pass   (NPAN = 2): panels k, k + 1 onto every column block from j_lo = k + 2 on: K = 128 per tile and pass.
+// Workgroup 0 of either factors diagonal block `diag` = j_lo (cd_factor_block applies the panel in front of it itself).
+struct TrailPass { int p0, j_lo, one_col, extra; };
+
+__device__ __forceinline__ void trail_decode(int t, const TrailPass& ps, int nS, int nP, int tri, int rp_blocks, int& i, int& j)
+{
+    if (ps.one_col) {
+        j = ps.j_lo;
+        if (t < nS) i = ps.j_lo + t;
+        else if (t < nS + nP) i = rp_blocks + (t - nS);
+        else { i = ps.j_lo + 1; j = ps.j_lo + 1; }
+    } else if (t < tri) {                            // S rows: row r = i - j_lo holds the tiles j = j_lo .. i
+        int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= t) ++r;
+        while (r * (r + 1) / 2 > t) --r;
+        i = ps.j_lo + r; j = ps.j_lo + (t - r * (r + 1) / 2);
+    } else {                                         // P H^T and nu rows: every column of the pass
+        const int u = t - tri;
+        i = rp_blocks + u / nS; j = ps.j_lo + u % nS;
+    }
+}
+
+template <int NPAN>
+__global__ void __launch_bounds__(CD_THREADS)
+trail_stream_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_t* __restrict__ sel, int slot_nblk,
+                    int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (blockIdx.x == 0) {
+        if (ps.j_lo >= rp_blocks) return;
+        CdPre pre;
+        cd_preload(pre, A, ldA, ps.j_lo, Linv, 1);
+        if (ps.j_lo < sel[slot_nblk])
+            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, ps.j_lo, sel, slot_k, Linv, status, 1, pre);
+        return;
+    }
+    const int nblk = sel[slot_nblk];
+    if (ps.j_lo >= nblk) return;                                  // no trailing matrix left
+    const int nS = nblk - ps.j_lo, nP = row_blocks - rp_blocks, tri = nS * (nS + 1) / 2;
+    const int total = ps.one_col ? nS + nP + ((ps.extra && ps.j_lo + 1 < nblk) ? 1 : 0) : tri + nP * nS;
+    const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1;
+    const int per = (total + W - 1) / W;
+    const int t0 = w * per, t1 = min(total, t0 + per);
+    if (t0 >= t1) return;                                         // (uniform over the workgroup, before any barrier)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), e = wave >> 2, wave4 = wave & 3;
+    const int tid = threadIdx.x & 255, row = tid & 63, g = tid >> 6;
+    double* hbase = lds + (long)e * TD_LDS_DOUBLES;
+    double* const Abuf[2] = { hbase, hbase + 2 * TD_OPER_DOUBLES };
+    double* const Bbuf[2] = { hbase + TD_OPER_DOUBLES, hbase + 3 * TD_OPER_DOUBLES };
+    const unsigned lo = td_lane_offset(ldA);
+    for (int tt = t0; tt < t1; tt += 2) {
+        const int t = tt + e;
+        const bool have = t < t1 && t != 0;                       // tile 0 = (j_lo, j_lo): the diagonal workgroup's own
+        int i, j;
+        trail_decode(t < t1 ? t : tt, ps, nS, nP, tri, rp_blocks, i, j);   // (an engine without a tile runs its sibling's: reads only)
+        const double* Xi = A + 64L * i + (long)ps.p0 * 64 * ldA;
+        const double* Xj = A + 64L * j + (long)ps.p0 * 64 * ldA;
+        double* C = A + 64L * i + 64L * j * ldA;
+        double cin[16];
+        if (have) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cin[q] = C[row + (long)(g + 4 * q) * ldA];
+        }
+        TgAcc acc;
+        tg_zero(acc);
+        double a[TG_MI];
+        BFrag b[TG_NI];
+        td_issue_chunk_w<0>(Xi, ldA, Xj, ldA, 0, Abuf[0], Bbuf[0], wave4);
+        __syncthreads();                                          // (waits for this wave's transfers -- and its tile)
+        td_read_frags(td_frag_ptr(Abuf[0], Bbuf[0], wave4), 0, a, b);
+        static_for<0, 2 * NPAN>([&](auto CC) {
+            constexpr int c = decltype(CC)::value, cur = c & 1, nxt = cur ^ 1;
+            if constexpr (c + 1 < 2 * NPAN)
+                td_compute_chunk_w<true, 0, 0>(Abuf[cur], Bbuf[cur], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, TG_KC * (c + 1), Abuf[nxt], Bbuf[nxt], wave4);
+            else
+                td_compute_chunk_w<false, 0, 0>(Abuf[cur], Bbuf[cur], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 0, Abuf[nxt], Bbuf[nxt], wave4);
+        });
+        __syncthreads();                                          // every fragment read
+        tg_acc_to_lds_w(acc, hbase, 1.0, wave4);                  // 64 x 65 staging over the first operand pair
+        __syncthreads();
+        if (have) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = g + 4 * q;
+                C[row + (long)c * ldA] = cin[q] - hbase[c * TS_LD + row];
+            }
+        }
+        __syncthreads();                                          // staging read before the next tile's transfers land in it
+    }
+}
+// The wide pass (two panels, K = 128) with its two engines half a tile apart: while one engine runs the four chunks of a
+// tile, the other writes its previous tile back and fetches its next one, so the matrix pipes of the compute unit see one
+// engine's MFMAs at a time, back to back, instead of both engines' followed by both engines' memory phases (the lock-step
+// form above: 35 TFLOP/s at C5's first pass).  A slot = the three chunk barriers of the computing engine; the other engine
+// matches them: (1) its accumulators are staged in the operand pair its tile finished with two chunks ago, (2) a bare
+// s_barrier -- its stores, the next tile and that tile's first operand chunk stay in flight -- and (3) the wait for them.
+// (Measured the same, C5 frame 2.440 ms against 2.441: both engines in step as one software pipeline -- the last chunk of a
+//  tile fetching the first chunk of the next, the write-back behind a bare s_barrier -- at 248 VGPRs; not kept.  Either way a
+//  K = 128 tile is ~6.5 us of engine time: 40 TFLOP/s chip-wide against the 58 of the rank update's K = 1664 loop.)
+__global__ void __launch_bounds__(CD_THREADS)
+trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_t* __restrict__ sel, int slot_nblk,
+                     int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (blockIdx.x == 0) {
+        if (ps.j_lo >= rp_blocks) return;
+        CdPre pre;
+        cd_preload(pre, A, ldA, ps.j_lo, Linv, 1);
+        if (ps.j_lo < sel[slot_nblk])
+            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, ps.j_lo, sel, slot_k, Linv, status, 1, pre);
+        return;
+    }
+    const int nblk = sel[slot_nblk];
+    if (ps.j_lo >= nblk) return;
+    const int nS = nblk - ps.j_lo, nP = row_blocks - rp_blocks, tri = nS * (nS + 1) / 2;
+    const int total = tri + nP * nS;
+    const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1;
+    const int per = (total + W - 1) / W;
+    const int t0 = w * per, t1 = min(total, t0 + per);
+    if (t0 >= t1) return;                                         // (uniform over the workgroup, before any barrier)
+    const int n = t1 - t0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), e = wave >> 2, wave4 = wave & 3;
+    const int tid = threadIdx.x & 255, row = tid & 63, g = tid >> 6;
+    const int n_mine = (n - e + 1) / 2;                           // this engine's tiles: t0 + e, t0 + e + 2, ...
+    double* hbase = lds + (long)e * TD_LDS_DOUBLES;
+    double* Ac = hbase;                                           // operand pair of chunks 0 and 2 of the tile in hand
+    double* Bc = hbase + TD_OPER_DOUBLES;
+    double* An = hbase + 2 * TD_OPER_DOUBLES;                     // ... of chunks 1 and 3
+    double* Bn = hbase + 3 * TD_OPER_DOUBLES;
+    const unsigned lo = td_lane_offset(ldA);
+    const double* Xi = A;                                         // operands and target of the tile in hand
+    const double* Xj = A;
+    double* C = A;
+    bool own = false;                                             // ... and whether it is this engine's to write
+    double cin[16], cnx[16];
+    TgAcc acc;
+    tg_zero(acc);
+    // fetch tile r of this engine: its values into `dst`, its first operand chunk into (Ad, Bd)
+    auto prepare = [&](int r, double (&dst)[16], double* Ad, double* Bd, const double*& xi, const double*& xj, double*& c, bool& mine) {
+        const int t = t0 + 2 * r + e;
+        int i, j;
+        trail_decode(t, ps, nS, nP, tri, rp_blocks, i, j);
+        xi = A + 64L * i + (long)ps.p0 * 64 * ldA;
+        xj = A + 64L * j + (long)ps.p0 * 64 * ldA;
+        c = A + 64L * i + 64L * j * ldA;
+        mine = t != 0;                                            // tile 0 = (j_lo, j_lo): the diagonal workgroup's own
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dst[q] = c[row + (long)(g + 4 * q) * ldA];
+        }
+        td_issue_chunk_w<0>(xi, ldA, xj, ldA, 0, Ad, Bd, wave4);
+    };
+    if (e == 0) prepare(0, cin, Ac, Bc, Xi, Xj, C, own);          // (n >= 1: engine 0 always has a tile)
+    __syncthreads();
+    for (int s = 0; s <= n; ++s) {
+        const int r = s >> 1;
+        if ((s & 1) == e) {
+            if (r < n_mine) {
+                // ---- compute: four chunks, three barriers
+                double a[TG_MI];
+                BFrag b[TG_NI];
+                tg_zero(acc);
+                td_read_frags(td_frag_ptr(Ac, Bc, wave4), 0, a, b);
+                td_compute_chunk_w<true, 0, 0>(Ac, Bc, acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 1 * TG_KC, An, Bn, wave4);
+                td_compute_chunk_w<true, 0, 0>(An, Bn, acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 2 * TG_KC, Ac, Bc, wave4);
+                td_compute_chunk_w<true, 0, 0>(Ac, Bc, acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 3 * TG_KC, An, Bn, wave4);
+                td_compute_chunk_w<false, 0, 0>(An, Bn, acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 0, Ac, Bc, wave4);
+            } else {
+                __syncthreads(); __syncthreads(); __syncthreads();
+            }
+        } else {
+            // ---- write the tile of the previous slot back, fetch the one of the next slot
+            const bool finish = s >= 1 && ((s - 1) >> 1) < n_mine;
+            const int rn = (s + 1) >> 1;
+            const bool more = rn < n_mine;
+            if (finish) tg_acc_to_lds_w(acc, Ac, 1.0, wave4);     // (Ac, Bc): read for the last time two chunks ago
+            __syncthreads();                                      // (1) staged; every wave of the engine is through its last chunk
+            double* Cw = C;
+            const bool ownw = own;
+            if (more) prepare(rn, cnx, An, Bn, Xi, Xj, C, own);
+            if (finish && ownw) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = g + 4 * q;
+                    Cw[row + (long)c * ldA] = cin[q] - Ac[c * TS_LD + row];
+                }
+            }
+            __builtin_amdgcn_s_barrier();                         // (2) matches the computing engine's second chunk: nothing to wait for here
+            __syncthreads();                                      // (3) stores out, next tile and its first chunk in
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cin[q] = cnx[q];
+                double* sw = Ac; Ac = An; An = sw;
+                sw = Bc; Bc = Bn; Bn = sw;
+            }
+        }
+    }
+}
+
+static_assert(TG_KC == 32, "trail_stream_kernel: a 64-column panel is two chunks");
+static_assert(2 * TD_OPER_DOUBLES >= TS_DOUBLES, "trail_stream_kernel stages a tile over one operand pair");
+
 // ---------------------------------------------------------------------------
 // K8, persistent form: the whole factor sweep of one update in ONE launch (systems whose workgroups are all
 // resident at once; launch_factor_sweep decides).  Launch boundaries are replaced by flags in global memory:
@@ -1626,6 +1836,7 @@ constexpr int CDP_TPRE_DOUBLES = 40 * 64;              // tile (k,k): lower 16 x
 constexpr size_t CDP_OFF_AOP = (sizeof(CdShared) + 15) / 16 * 2;     // in doubles
 constexpr size_t SWP_CHAIN_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
 constexpr size_t SWP_LDS_BYTES = SWP_CHAIN_LDS_BYTES > sizeof(double) * 2 * TD_LDS_DOUBLES ? SWP_CHAIN_LDS_BYTES : sizeof(double) * 2 * TD_LDS_DOUBLES;   // tile workers: two engines
+static_assert(SWP_LDS_BYTES >= sizeof(CdShared), "trail_stream_kernel: the diagonal workgroup shares the launch's LDS size");
 
 
 // compile-time loop: the accumulator array of a strip must never be indexed dynamically (it would move to scratch)
@@ -2904,6 +3115,12 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
@@ -3010,14 +3227,48 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
         return Ystore;
     }
     if ((long)row_blocks * steps > 512) {
-        // large system: panel once per step, then trailing update + next diagonal block in one launch
+        // large system: panel once per step; the trailing update as a stream, two panels per pass (trail_stream_kernel)
+        // (steps is the update's exact block count here -- the host has read it: enqueue_update -- or an upper bound: the
+        //  kernels deal out the tiles of the device-side count, the grids only bound the number of workgroups)
         if (steps <= 0) return A;
+        static const bool tiles = getenv("RSLAM_TRAIL_TILES") != nullptr;     // measurement: one workgroup per tile, one panel per pass
+        static const bool w1 = getenv("RSLAM_TRAIL_W1") != nullptr;           // measurement: the stream with one panel per pass
+        const int cus = device_cus();
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
-        for (int step = 0; step < steps; ++step) {
+        auto stream_pass = [&](int npan, const TrailPass& ps) {
+            const long nS = steps - ps.j_lo, nP = row_blocks - rp_blocks;
+            const long total = ps.one_col ? nS + nP + 1 : nS * (nS + 1) / 2 + nP * nS;
+            long W = (total + 1) / 2;
+            if (W > cus - 1) W = cus - 1;
+            if (W < 1) W = 1;
+            static const bool lockstep = getenv("RSLAM_TRAIL_LOCKSTEP") != nullptr;      // measurement: both engines in the same phase
+            if (npan == 2 && !lockstep) trail_stream2_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+            else if (npan == 2) trail_stream_kernel<2><<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+            else trail_stream_kernel<1><<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+        };
+        int step = 0;
+        while (step < steps) {
             panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
-            if (step + 1 < steps)
+            if (step + 1 >= steps) break;
+            if (tiles || cus < 2) {
                 trail_diag_kernel<<<dim3(1 + row_blocks * (steps - step - 1)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
                     A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+                ++step;
+            } else if (w1) {
+                stream_pass(1, TrailPass{step, step + 1, 0, 0});
+                ++step;
+            } else if (step + 2 < steps) {
+                stream_pass(1, TrailPass{step, step + 1, 1, 1});          // panel k onto column k+1 (+ the next diagonal tile)
+                panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step + 1, sel, slot_nblk, Linv, rp_blocks);
+                stream_pass(2, TrailPass{step, step + 2, 0, 0});          // panels k, k+1 onto everything from column k+2 on
+                step += 2;
+            } else {
+                stream_pass(1, TrailPass{step, step + 1, 1, 0});          // the last column
+                ++step;
+            }
         }
         return A;
     }
