@@ -1515,6 +1515,16 @@ trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
     trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
 }
 
+// compile-time loop: an accumulator array must never be indexed dynamically (it would move to scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // The trailing update as a stream (what large systems run).  The tiles of a pass, row-major over the active rows, are dealt
 // out in contiguous ranges to at most (compute units - 1) workgroups, and the two four-wave engines of a workgroup take
 // alternate tiles of its range: two tiles in flight per compute unit instead of one (trail_diag_kernel retires half of its
@@ -1838,16 +1848,6 @@ constexpr size_t SWP_CHAIN_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_D
 constexpr size_t SWP_LDS_BYTES = SWP_CHAIN_LDS_BYTES > sizeof(double) * 2 * TD_LDS_DOUBLES ? SWP_CHAIN_LDS_BYTES : sizeof(double) * 2 * TD_LDS_DOUBLES;   // tile workers: two engines
 static_assert(SWP_LDS_BYTES >= sizeof(CdShared), "trail_stream_kernel: the diagonal workgroup shares the launch's LDS size");
 
-
-// compile-time loop: the accumulator array of a strip must never be indexed dynamically (it would move to scratch)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // Eight waves: wave = 4 g + w.  Group g owns the column blocks j = 2 jj + g, wave w the columns 16 w .. 16 w + 15 of each.
 // column c of P H^T for the update at hand (row index = state index): gathered from the matched-feature matrix (LI pass)
