@@ -685,6 +685,9 @@ void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* 
 // K6: stacked system A = [S ; P H^T ; nu^T] of the flagged features
 // (ExtendKF.cpp:565-594 stack z, h, H; :602 S = H P H^T + I).
 // ---------------------------------------------------------------------------
+// STAGED: the P H^T column of the workgroup goes through LDS (dynamic, NP doubles): the 13-term dots of its S entries gather
+// from there instead of from global memory (C5: 97 -> 3x µs for the HI system; the dependent gathers were the kernel)
+template <bool STAGED>
 __global__ void __launch_bounds__(256)
 prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int32_t* __restrict__ sel,
                       int slot_k, int slot_nblk, const double* __restrict__ H13, const int32_t* __restrict__ off,
@@ -693,6 +696,7 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
                       const double* __restrict__ Wsrc /* nullable */, const int32_t* __restrict__ rank_of,
                       int32_t* __restrict__ sweep_flags /* nullable */)
 {
+    extern __shared__ __attribute__((aligned(16))) double s_col[];
     const int c = blockIdx.x;
     if (sweep_flags && c == 0 && threadIdx.x < SWEEP_FLAG_INTS) sweep_flags[threadIdx.x] = 0;   // hand-over flags of the persistent sweep
     if (c >= 64 * sel[slot_nblk]) return;
@@ -701,9 +705,13 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
     double* wcol = col + d.RP;                  // P*H^T column c
     if (Wsrc && c < r) {                        // low-innovation pass: gather it from the matched-feature P*H^T
         const double* src = Wsrc + (long)(2 * rank_of[list[c >> 1]] + (c & 1)) * d.NP;
-        for (int a = threadIdx.x; a < d.NP; a += 256) wcol[a] = src[a];
+        for (int a = threadIdx.x; a < d.NP; a += 256) { const double v = src[a]; wcol[a] = v; if (STAGED) s_col[a] = v; }
         __syncthreads();                        // the block re-reads its own column below
+    } else if (STAGED && c < r) {
+        for (int a = threadIdx.x; a < d.NP; a += 256) s_col[a] = wcol[a];
+        __syncthreads();
     }
+    const double* gsrc = STAGED ? s_col : wcol;
     for (int a = threadIdx.x; a < d.RP; a += 256) {
         double v = (a == c) ? 1.0 : 0.0;        // + R = I (ExtendKF.cpp:594); identity on the padding
         if (c < r && a < r) {
@@ -712,7 +720,7 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
             const int o = off[fa];
             const int w = (type[fa] == 0) ? 13 : 10;
             double sacc = 0;
-            for (int k = 0; k < w; ++k) sacc += Hf[k] * wcol[col_index(o, k)];
+            for (int k = 0; k < w; ++k) sacc += Hf[k] * gsrc[col_index(o, k)];
             v += sacc;
         }
         col[a] = v;
@@ -734,8 +742,13 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
                            const double* Wsrc, const int32_t* rank_of, int32_t* sweep_flags)
 {
     if (d.RP <= 0) return;
-    prepare_system_kernel<<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A, Wsrc, rank_of,
-                                                         sweep_flags);
+    const size_t bytes = sizeof(double) * (size_t)d.NP;
+    if (bytes <= 64 * 1024)
+        prepare_system_kernel<true><<<dim3(d.RP), dim3(256), bytes, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A, Wsrc, rank_of,
+                                                                      sweep_flags);
+    else
+        prepare_system_kernel<false><<<dim3(d.RP), dim3(256), 0, s>>>(d, list, sel, slot_k, slot_nblk, H13, off, type, z, h, A, Wsrc, rank_of,
+                                                                    sweep_flags);
 }
 
 // ---------------------------------------------------------------------------
