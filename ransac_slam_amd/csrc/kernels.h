@@ -134,14 +134,21 @@ struct XuArgs {
     int compat; int token; int32_t* flag;
     int riders_first;           // != 0: the x update in front of the tiles whatever the occupancy says (re-run after a timed-out Jnorm wait)
     int inject;                 // fault injection (tests): riders placed behind the tiles never publish Jnorm
+    // deferred low-innovation covariance on the stand-alone path (rank <= 4, decided by the host from the frame's counts): the
+    // launch is the x update alone -- the riders also keep the four columns of Y aside and group 0 sets *defer_flag -- and the
+    // covariance is materialised by the HI pass (MatArgs): one stream over P less (134 us at C5)
+    int riders_only; double* Y1out; long ldy1; int32_t* defer_flag;
 };
+// What the tiles of the stand-alone rank update need to start from a deferred P_li (SEL_LI_DEFER) instead of Pin:
+// M = 1/2 (P_pred + P_pred^T) - Y1 Y1^T, then the Jnorm congruence of the low-innovation update (T_li) on rows / columns 3..6
+struct MatArgs { const int32_t* flag; const double* Ppred; long ldp; const double* Y1; long ldy1; const double* T_li; };
 // C = sym(Pin) - Y Y^T on the lower-triangle tile pairs (K from sel[slot_nblk]*64);
 // K == 0: C = Pin exactly (ExtendKF.cpp:635-638 pass-through)
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
                         const int32_t* tile_order /* nullable: row-major triangle */,
                         const double* Tq /* nullable: 4 x 4 Jnorm, applied to rows/columns 3..6 (K11) when sel[slot_k] != 0 */,
-                        int slot_k, const XuArgs* xu /* nullable */);
+                        int slot_k, const XuArgs* xu /* nullable */, const MatArgs* mat = nullptr /* HI pass: P_li may be deferred */);
 void make_rank_update_order(int nT, std::vector<int32_t>& order);   // XCD-aware (bi << 16 | bj) per block
 
 // x_pred[0:13], FQ (338 doubles) and the 13-row/column strips of P_pred; the caller copies

@@ -3303,7 +3303,8 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
 __device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int32_t* __restrict__ sel, int slot_nblk, int slot_k,
                                              const double* __restrict__ A, const double* __restrict__ x_in,
                                              double* __restrict__ x_out, double* __restrict__ T, int compat,
-                                             int32_t* flag, int token, double (*part)[17])
+                                             int32_t* flag, int token, double (*part)[17],
+                                             double* __restrict__ Y1out = nullptr, long ldy1 = 0, int32_t* defer_flag = nullptr)
 {
     // 16 rows x 16 K-slices per workgroup; fixed-order LDS reduction (bitwise reproducible)
     const int K = 64 * sel[slot_nblk];
@@ -3315,6 +3316,9 @@ __device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int3
 #pragma unroll 8
     for (int k = sl; k < K; k += 16) acc += Y[row + (long)k * d.ldA] * u[(long)k * d.ldA];     // (eight load pairs in flight)
     part[sl][r] = acc;
+    // deferred covariance: the (at most four) columns of Y are kept aside (the padding columns of the system are zero)
+    if (Y1out && sl < 4) Y1out[row + (long)sl * ldy1] = Y[row + (long)sl * d.ldA];
+    if (defer_flag && group == 0 && threadIdx.x == 0) *defer_flag = 1;
     __syncthreads();
     if (sl == 0) {
         double ssum = 0;
@@ -3352,10 +3356,61 @@ __device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int3
 // = ExtendKF.cpp:608-609 (P - K S K^T, then 1/2 (P + P^T)) with K S K^T = Y Y^T.
 // Safe in place: a workgroup owns both tiles of its pair.
 // ---------------------------------------------------------------------------
+// The Jnorm congruence (ExtendKF.cpp:629-634) on an LDS tile Cs[col][row] of the first block column: tile (bi, 0) has its
+// columns 3..6 mixed, tile (0, 0) rows and columns (its 4 x 4 block symmetrised afterwards, as the reader of an immediate P_li
+// would see it); every thread of the 256 calls it; ends behind a barrier.
+__device__ __forceinline__ void k11_lds(double* Cs, const double (&T)[16], int bi)
+{
+    const int j = threadIdx.x;
+    if (bi != 0) {
+        if (j < 64) {
+            double rb[4];
+            for (int i = 0; i < 4; ++i) {
+                double sacc = 0;
+                for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + k) * TS_LD + j];
+                rb[i] = sacc;
+            }
+            for (int i = 0; i < 4; ++i) Cs[(3 + i) * TS_LD + j] = rb[i];
+        }
+    } else {
+        if (j < 64 && !(j >= 3 && j < 7)) {
+            double rb[4];
+            for (int i = 0; i < 4; ++i) {
+                double sacc = 0;
+                for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[j * TS_LD + (3 + k)];
+                rb[i] = sacc;
+            }
+            for (int i = 0; i < 4; ++i) { Cs[j * TS_LD + (3 + i)] = rb[i]; Cs[(3 + i) * TS_LD + j] = rb[i]; }
+        } else if (j == 3) {
+            double cb[4][4], out[4][4];         // cb = J * P44 ; out = cb * J^T
+            for (int i = 0; i < 4; ++i)
+                for (int c = 0; c < 4; ++c) {
+                    double sacc = 0;
+                    for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + c) * TS_LD + (3 + k)];
+                    cb[i][c] = sacc;
+                }
+            for (int i = 0; i < 4; ++i)
+                for (int c = 0; c < 4; ++c) {
+                    double sacc = 0;
+                    for (int k = 0; k < 4; ++k) sacc += cb[i][k] * T[c + 4 * k];
+                    out[i][c] = sacc;
+                }
+            // (the pass that reads an immediate P_li takes 1/2 (P + P^T) of what the congruence left: the same here)
+            for (int i = 0; i < 4; ++i)
+                for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = 0.5 * out[i][c] + 0.5 * out[c][i];
+        }
+    }
+    __syncthreads();
+}
+
+// MAT: the pass may have to start from a deferred P_li (MatArgs); an instantiation of its own so that the plain pass keeps its
+// register count (two workgroups per compute unit)
+template <bool MAT>
 __global__ void __launch_bounds__(256)
 rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict__ Y, long ldy,
                    const int32_t* __restrict__ sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
                    const int32_t* __restrict__ tile_order, const double* __restrict__ Tq /* nullable */, int slot_k, XuArgs xu,
+                   MatArgs mat,
                    int rider0 /* first workgroup of the x update: 0 (then the tiles follow) or the number of tiles */,
                    unsigned long long* dbg /* nullable: [workgroup][4] = start, K loop entered, K loop done, end (100 MHz) + hw id */)
 {
@@ -3367,9 +3422,11 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
         // (xu.inject: fault injection for the tests -- riders dispatched behind the tiles never publish Jnorm, as if rider 0 had
         //  not found a slot: the first block column must run into its bounded wait and the host must re-run with the riders first)
         xupdate_rows((int)blockIdx.x - rider0, xu.d, sel, slot_nblk, slot_k, xu.A, xu.x_in, xu.x_out, xu.T, xu.compat,
-                     (xu.inject && rider0 != 0) ? nullptr : xu.flag, xu.token, reinterpret_cast<double (*)[17]>(lds));
+                     (xu.inject && rider0 != 0) ? nullptr : xu.flag, xu.token, reinterpret_cast<double (*)[17]>(lds),
+                     xu.Y1out, xu.ldy1, xu.defer_flag);
         return;
     }
+    if (xu.riders_only) return;
     const int tile_index = rider0 == 0 ? (int)blockIdx.x - xu.groups : (int)blockIdx.x;
     if (dbg && threadIdx.x == 0) {
         dbg[8L * blockIdx.x + 0] = wall_clock64();
@@ -3394,11 +3451,14 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     (void)nT;
     const int K = (fixed_k >= 0) ? fixed_k : 64 * sel[slot_nblk];
     const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+    // P_li deferred (MatArgs): this pass starts from P_pred and forms P_li = J (sym(P_pred) - Y1 Y1^T) J^T on the way
+    const bool deferred = MAT && mat.flag && *mat.flag != 0;        // (uniform)
+    if (deferred) { Pin = mat.Ppred; ldp = mat.ldp; }
     const double* Pij = Pin + (long)bi * 64 + (long)bj * 64 * ldp;
     const double* Pji = Pin + (long)bj * 64 + (long)bi * 64 * ldp;
     double* Cij = Pout + (long)bi * 64 + (long)bj * 64 * ldo;
     double* Cji = Pout + (long)bj * 64 + (long)bi * 64 * ldo;
-    if (K == 0) {                                   // update() pass-through, ExtendKF.cpp:635-638
+    if (K == 0 && !deferred) {                      // update() pass-through, ExtendKF.cpp:635-638
         if (Pin != Pout) {
             for (int q = 0; q < 16; ++q) {
                 const int c = g + 4 * q;
@@ -3411,7 +3471,7 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     // The HI pass reads what the LI pass wrote: mirrored tile pairs, i.e. exactly symmetric off the diagonal tiles, so
     // 1/2 (P + P^T) = P there bit for bit and the mirror tile need not be read (a quarter of this pass's reads).  Not
     // when the LI pass was a pass-through (no inliers: its output is the prior as uploaded).
-    const bool mirror_known = (xu.token == 2) && (bi != bj) && (sel[SEL_NBLK_LI] > 0);
+    const bool mirror_known = !deferred && (xu.token == 2) && (bi != bj) && (sel[SEL_NBLK_LI] > 0);
     // Both P tiles are requested before the K loop and land under it: the epilogue is left with the stores only.
     double pij[16], pji[16];
 #pragma unroll
@@ -3427,17 +3487,51 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     if (dbg && threadIdx.x == 0) dbg[8L * blockIdx.x + 2] = wall_clock64();
     double* Cs = lds;
     double* Ts = lds + TS_DOUBLES;
+    double* Y1s = lds + 2 * TS_DOUBLES;             // 64 x 4 of block bj (deferred)
+    double y1i[4] = {0.0, 0.0, 0.0, 0.0}, y1j = 0.0, Tli[16];
+    if (MAT && deferred) {                          // (after the K loop: nothing of this lives in registers across it)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) y1i[cc] = mat.Y1[64L * bi + row + cc * mat.ldy1];
+        y1j = mat.Y1[64L * bj + row + g * mat.ldy1];                 // thread (row, g): entry (row, g) of the 64 x 4 block of bj
+        if (bj == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Tli[k] = mat.T_li[k];
+        }
+    }
     tg_acc_to_lds(acc, Cs, 1.0);
     if (!mirror_known) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) Ts[(g + 4 * q) * TS_LD + row] = pji[q];       // tile (bj,bi), element (row, c) -> Ts[c][row]
     }
+    if (MAT && deferred) Y1s[row + 64 * g] = y1j;
     __syncthreads();
+    double m[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = g + 4 * q;
         const double pm = mirror_known ? pij[q] : Ts[row * TS_LD + c];           // P(bj,bi)[c, row]
-        const double o = (0.5 * pij[q] + 0.5 * pm) - Cs[c * TS_LD + row];
+        m[q] = 0.5 * pij[q] + 0.5 * pm;
+    }
+    if (MAT && deferred) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = g + 4 * q;
+            m[q] -= (y1i[0] * Y1s[c] + y1i[1] * Y1s[c + 64]) + (y1i[2] * Y1s[c + 128] + y1i[3] * Y1s[c + 192]);
+        }
+        if (bj == 0) {                              // Jnorm of the low-innovation update on rows / columns 3..6 of M
+            __syncthreads();                        // (Ts read by everybody)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) Ts[(g + 4 * q) * TS_LD + row] = m[q];
+            __syncthreads();
+            k11_lds(Ts, Tli, bi);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m[q] = Ts[(g + 4 * q) * TS_LD + row];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        const double o = m[q] - Cs[c * TS_LD + row];
         Cij[row + (long)c * ldo] = o;
         Cs[c * TS_LD + row] = o;
     }
@@ -3546,13 +3640,20 @@ int debug_k10_stamps(unsigned long long* out /* K10_DBG_WGS * 8, nullable */, in
 
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                        const int32_t* tile_order, const double* Tq, int slot_k, const XuArgs* xu)
+                        const int32_t* tile_order, const double* Tq, int slot_k, const XuArgs* xu, const MatArgs* mat)
 {
     const int nT = NP / 64;
-    const int tiles = nT * (nT + 1) / 2;
+    int tiles = nT * (nT + 1) / 2;
     if (tiles <= 0) return;
     XuArgs none{}; none.groups = 0;
     const XuArgs& x = xu ? *xu : none;
+    MatArgs m{}; if (mat) m = *mat;
+    if (x.riders_only) {                            // the x update alone (deferred covariance): no tile workgroups at all
+        if (x.groups <= 0) return;
+        rank_update_kernel<false><<<dim3(x.groups), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
+                                                                                     fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, m, 0, nullptr);
+        return;
+    }
     // Where the x update rides: in front of the tiles (dispatched first: its Jnorm is out long before the tiles of the first
     // block column ask for it) -- unless every tile finds a slot at once (two workgroups per CU) and slots are left over:
     // then the riders go last, group 0 still starts at once, and no tile waits for a rider to vacate its slot (the late
@@ -3561,7 +3662,7 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
     static int slots = -1;
     if (slots < 0) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rank_update_kernel), 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rank_update_kernel<false>), 256,
                                                          sizeof(double) * TG_LDS_DOUBLES) != hipSuccess) per_cu = 0;
         slots = per_cu * device_cus();
     }
@@ -3569,9 +3670,14 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
     // behind the tiles only when tiles AND riders all find a slot at once (then rider 0 is resident whatever the dispatch order);
     // x.riders_first: the host saw a timed-out Jnorm wait (somebody else holds compute units) and re-runs the safe order
     const int rider0 = (x.groups > 0 && tiles + x.groups <= slots && !riders_first && !x.riders_first) ? tiles : 0;
-    rank_update_kernel<<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
-                                                                                             fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, rider0,
-                                                                                             (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);
+    if (mat)
+        rank_update_kernel<true><<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
+                                                                                                   fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, m, rider0,
+                                                                                                   (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);
+    else
+        rank_update_kernel<false><<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
+                                                                                                    fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, m, rider0,
+                                                                                                    (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -3729,12 +3835,14 @@ void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const doub
 int init_kernel_attributes2()
 {
     const int bytes = (int)(sizeof(double) * TG_LDS_DOUBLES);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_update_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_update_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (getenv("RSLAM_DEBUG_OCCUPANCY")) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(rank_update_kernel), 256, (size_t)bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(rank_update_kernel<false>), 256, (size_t)bytes);
         fprintf(stderr, "[rslam] rank_update_kernel: %d workgroups per CU at %d B of dynamic LDS\n", nb, bytes);
     }
     return (int)e;

@@ -67,6 +67,7 @@ struct rslam_ctx {
     // device buffers
     DevBuf<uint8_t> d_type, d_vis, d_hash, d_hash2, d_ic, d_li, d_hi, d_mtype;
     DevBuf<int32_t> d_tile_order;
+    bool li_defer_host = false;                  // this frame's LI update (stand-alone path) leaves its covariance deferred
     int tile_order_nT = 0;
     DevBuf<int32_t> d_off, d_mfeat, d_moff, d_mith, d_miph, d_mzsrc, d_rank_of, d_pos, d_nhyp,
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
@@ -527,12 +528,19 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         // K9 (x_k_k = x + Y u, quaternion normalisation, Jnorm) rides in the rank-update launch
         XuArgs xu{};
         xu.groups = c->RP > 0 ? c->NP / 16 : 0;
-        xu.d = d; xu.A = Ysys; xu.x_in = x_in; xu.x_out = x_out; xu.T = c->d_T.p; xu.compat = c->cfg.compat;
+        // (Jnorm of the LI update at d_T, of the HI update behind it: the HI pass may still need the LI one -- deferred covariance)
+        double* Tq = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
+        xu.d = d; xu.A = Ysys; xu.x_in = x_in; xu.x_out = x_out; xu.T = Tq; xu.compat = c->cfg.compat;
         xu.token = (slot_k == SEL_K_LI) ? 1 : 2;              // sel[] is zeroed at the start of a frame (predict_kernel)
         xu.flag = sel + SEL_XU_FLAG;
         xu.riders_first = c->k10_riders_first ? 1 : 0; xu.inject = c->k10_inject;
+        if (slot_k == SEL_K_LI && c->li_defer_host && xu.groups > 0) {
+            // rank <= 4 (the host has read the count: enqueue_update): the x update alone; P_li stays implicit until the HI pass
+            xu.riders_only = 1; xu.Y1out = c->d_Y1.p; xu.ldy1 = c->NP; xu.defer_flag = sel + SEL_LI_DEFER;
+        }
+        const MatArgs mat{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p};
         launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
-                           order, c->RP > 0 ? c->d_T.p : nullptr, slot_k, &xu);
+                           order, c->RP > 0 ? Tq : nullptr, slot_k, &xu, slot_k == SEL_K_HI ? &mat : nullptr);
     }
     if (ev_r1 >= 0) mark(c, ev_r1);
     return RSLAM_OK;
@@ -562,11 +570,15 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     // sequence per block step, and how many steps an update needs is only known on the device.  The host reads that one
     // integer here (a ~15 us round trip in a frame of milliseconds) and enqueues exactly that many: no sizing from the
     // previous frame, no overflow, no re-run, no hipGraph re-capture.  Such frames are therefore not captured into graphs.
+    c->li_defer_host = false;
     if (!persistent) {
-        int32_t nb = 0;
-        HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_LI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        int32_t cnt[SEL_NBLK_LI - SEL_K_LI + 1] = {0};            // sel[SEL_K_LI .. SEL_NBLK_LI]
+        HIPCHK(hipMemcpyAsync(cnt, sel + SEL_K_LI, sizeof(cnt), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        cap_li = nb;
+        cap_li = cnt[SEL_NBLK_LI - SEL_K_LI];
+        // a low-innovation update of rank <= 4 (compat mode: Q1 leaves one or two inliers) does not stream P: kernels.h MatArgs
+        static const bool no_defer = getenv("RSLAM_NO_LI_DEFER") != nullptr;       // measurement
+        c->li_defer_host = !no_defer && cnt[0] >= 1 && 2 * cnt[0] <= 4 && c->RP > 0;
     }
     // low-innovation update (ExtendKF.cpp:559-596)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
@@ -1534,7 +1546,10 @@ extern "C" int rslam_debug_update_mode(rslam_ctx* c)
     if (!sweep_is_persistent(c)) return 0;
     return sweep_fused_eligible(d) ? 2 : 1;
 }
-// diagnostics / fault injection (not part of include/rslam.h): RSLAM_SWEEP_EXP switches from the host, -1 = environment
+// diagnostics / fault injection (not part of include/rslam.h): RSLAM_SWEEP_EXP switches from the host, -1 = environment.
+// PROCESS-WIDE, like the two stamp buffers below (one per process, the last stamped launch wins): these entry points exist for
+// the tests and scripts of this repository, which drive one context at a time; they are not synchronised against contexts of
+// other threads and a product build would compile them out.  Everything the product path reads is per context.
 extern "C" int rslam_debug_set_sweep_exp(int mask) { rslam::set_sweep_exp_mask(mask); return RSLAM_OK; }
 // fault injection (tests), per context: riders of the stand-alone rank update that sit behind the tiles never publish Jnorm
 extern "C" int rslam_debug_set_k10_inject(rslam_ctx* c, int on) { if (!c) return RSLAM_ERR_ARG; c->k10_inject = on ? 1 : 0; invalidate_graph(c); return RSLAM_OK; }

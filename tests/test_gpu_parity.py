@@ -532,6 +532,28 @@ def test_c3_full_size_against_structured_oracle(hip, oracle_lib, compat):
     g.close(); g2.close()
 
 
+def test_large_system_route_against_oracle(hip, oracle_lib):
+    """500 landmarks (n = 3013): 260 strips, one too many for the persistent sweep, so the update stage runs the route of the
+    large systems -- launch-per-step sweep sized by the host from the frame's counts, trailing update as a stream with two
+    block steps per wide pass, stand-alone rank update -- at a size the oracle still does in seconds.  In compat mode the
+    low-innovation update has one or two inliers: its covariance stays deferred on this route too (the x update alone, the
+    HI pass starts from P_pred: kernels.h MatArgs)."""
+    fr = make_frame(L=500, H=300, seed=11)
+    for compat in (1, 0):
+        cfg = default_config(compat=compat, adaptive=0)
+        o, g, r0, r1 = run_both(hip, oracle_lib, fr, cfg, structure=1)
+        assert g.debug_update_mode() == 0                       # the launch-per-step route
+        check_frame(o, g, r0, r1)
+        n_li, n_hi = int(r1["li"].sum()), int(r1["hi"].sum())
+        if compat == 1:
+            assert 1 <= n_li <= 2 and n_hi > 100                # the deferred low-innovation covariance
+        else:
+            assert n_li > 100                                    # several block steps in the LI sweep as well
+        c = g.counters()
+        assert c["sweep_reruns"] == 0 and c["graph_captures"] == 0
+        g.close()
+
+
 @pytest.mark.parametrize("compat", [1, 0])
 def test_c5_against_oracle_fixture(hip, compat):
     """BASELINE config C5 (1000 landmarks, n = 6013, 1000 hypotheses) against the oracle: tests/golden/c5/*.npz hold the
