@@ -36,6 +36,13 @@ struct DeferArgs {
                               // written by the rescue prediction, read by the second P H^T
 };
 
+// The rescue gate (Tracking.cpp:584-595) without a launch of its own: the rescue prediction decides every feature's flag
+// (GateArgs: the group that has just produced S_i and h_i evaluates nu' S^-1 nu < chi2 for it) and every workgroup of the
+// second P H^T finds its feature -- the c-th flagged one -- and the count from the L flag bytes itself (GateList: a ballot scan,
+// two barriers per 256 features); its first workgroups write the ordered list and the counts the HI sweep reads.
+struct GateArgs { const uint8_t* ic; const uint8_t* li; const double* z; double chi2; uint8_t* hi; };
+struct GateList { const uint8_t* flags; int L; int32_t* list_out; int32_t* sel; int cap_blocks; };
+
 struct ScoreTables {          // per matched feature (rank j in feature order), m entries each
     const int32_t* feat;      // feature index
     const int32_t* off;       // state offset of the feature
@@ -50,7 +57,8 @@ struct ScoreTables {          // per matched feature (rank j in feature order), 
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
                     const uint8_t* type, const int32_t* off, const double* h_in, const uint8_t* has_h_in,
                     double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset,
-                    const DeferArgs* defer = nullptr /* P is P_li: possibly deferred (rescue prediction) */);
+                    const DeferArgs* defer = nullptr /* P is P_li: possibly deferred (rescue prediction) */,
+                    const GateArgs* gate = nullptr /* with defer: the rescue flags hi[] in the same launch */);
 
 // out[:, 2c+p] = P[:, cols(list[c])] * H13[list[c]][p]^T for c < count; with wv != nullptr also
 // wv[2c..] = S_f^-1 (z_f - h_f) (K3)
@@ -59,7 +67,8 @@ void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int
                 const uint8_t* type, double* out, long ldo, const double* S, const double* z, const double* h,
                 const uint8_t* has_h, double* wv, int32_t* status,
                 const double* x = nullptr, const int32_t* ith = nullptr, const int32_t* iph = nullptr, double* sc = nullptr /* with wv:
-                the angle table of ScoreTables::sc */, const DeferArgs* defer = nullptr /* P is P_li: possibly deferred */);
+                the angle table of ScoreTables::sc */, const DeferArgs* defer = nullptr /* P is P_li: possibly deferred */,
+                const GateList* gl = nullptr /* with defer: list / count come from the rescue flags (no launch_rescue_gate) */);
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                   const double* wv, const ScoreTables& tab, const double* z, int m, int words,

@@ -34,13 +34,14 @@ namespace rslam {
 // Two waves per four features: the kernel is ONE instruction stream of ~1900 vector instructions per feature (it runs at
 // 75 waves on 1024 SIMDs: its duration is that stream).  Wave 1 runs the part of the Jacobian that does not need the
 // predicted pixel (jacobian_core, ~860 instructions) while wave 0 runs the prediction (~830) and hands it over through LDS.
-template <bool CAN_DEFER>      // (false: the frame's first prediction -- P is the prior as it stands: none of the deferral code)
+// GATE (rescue prediction): the group also decides the feature's rescue flag hi[i] (GateArgs) from the S, h it has just produced.
+template <bool CAN_DEFER, bool GATE>      // (false: the frame's first prediction -- P is the prior as it stands: none of the deferral code)
 __global__ void __launch_bounds__(128)
 predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ P, int NP, int L,
                const uint8_t* __restrict__ type, const int32_t* __restrict__ off,
                const double* __restrict__ h_in, const uint8_t* __restrict__ has_h_in,   // nullable: no previous h
                double* __restrict__ h, uint8_t* __restrict__ has_h, uint8_t* vis, double* __restrict__ H13,
-               double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */, DeferArgs da)
+               double* __restrict__ S, double radd, int32_t* __restrict__ sel_reset /* nullable */, DeferArgs da, GateArgs ga)
 {
     __shared__ double sB[4][26];
     if (sel_reset && blockIdx.x == 0 && threadIdx.x < SEL_COUNT) {   // new frame: the frame scalars start from zero ...
@@ -93,6 +94,9 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
             for (int c = 0; c < 4; ++c) y1[c] = da.Y1[col_index(o, sub) + (long)c * da.ldy];
         }
     }
+    bool cand = false;
+    double gz0 = 0.0, gz1 = 0.0;
+    if (GATE && live) { cand = ga.ic[i] && !ga.li[i]; gz0 = ga.z[2 * i]; gz1 = ga.z[2 * i + 1]; }
     double u = 0, v = 0;
     const bool visible = live && predict_feature(cam, x, o, is_id, u, v);
     const bool had = live && has_h_in && (has_h_in[i] != 0);
@@ -105,7 +109,10 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
         if (vis) vis[i] = visible ? 1 : 0;
     }
     __syncthreads();                         // the other wave's half of the Jacobian is in LDS
-    if (!have) return;
+    if (!have) {
+        if (GATE && live && sub == 0) ga.hi[i] = 0;
+        return;
+    }
     const bool deferred = CAN_DEFER && dflag != 0;                   // (uniform)
     if (CAN_DEFER && deferred) {
 #pragma unroll
@@ -174,22 +181,38 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
     }
     if (sub == 0) {
         S[4 * i + 0] = s00 + radd; S[4 * i + 1] = s10; S[4 * i + 2] = s01; S[4 * i + 3] = s11 + radd;
+        if (GATE) {                              // nu' S^-1 nu < chi2 (Tracking.cpp:589-593), as rescue_gate_kernel evaluates it
+            bool rescue = false;
+            if (cand) {
+                double Si[4] = { s00 + radd, s10, s01, s11 + radd }, Sinv[4];
+                inv2_lu(Si, Sinv);
+                const double n0 = gz0 - hu_, n1 = gz1 - hv_;
+                const double t0g = n0 * Sinv[0] + n1 * Sinv[1];
+                const double t1g = n0 * Sinv[2] + n1 * Sinv[3];
+                rescue = (t0g * n0 + t1g * n1) < ga.chi2;
+            }
+            ga.hi[i] = rescue ? 1 : 0;
+        }
     }
 }
 
 void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double* P, int NP, int L,
                     const uint8_t* type, const int32_t* off, const double* h_in, const uint8_t* has_h_in,
-                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset, const DeferArgs* defer)
+                    double* h, uint8_t* has_h, uint8_t* vis, double* H13, double* S, double radd, int32_t* sel_reset, const DeferArgs* defer,
+                    const GateArgs* gate)
 {
     DeferArgs da{}; if (defer) da = *defer;
+    GateArgs ga{}; if (gate) ga = *gate;
     if (L <= 0) {
         if (sel_reset) (void)hipMemsetAsync(sel_reset, 0, sizeof(int32_t) * SEL_COUNT, s);
         return;
     }
-    if (defer) predict_kernel<true><<<dim3((L + 3) / 4), dim3(128), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
-                                                                         sel_reset, da);
-    else predict_kernel<false><<<dim3((L + 3) / 4), dim3(128), 0, s>>>(cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd,
-                                                                     sel_reset, da);
+    const dim3 grid((L + 3) / 4), block(128);
+#define PREDICT_ARGS cam, x, P, NP, L, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd, sel_reset, da, ga
+    if (defer && gate) predict_kernel<true, true><<<grid, block, 0, s>>>(PREDICT_ARGS);
+    else if (defer) predict_kernel<true, false><<<grid, block, 0, s>>>(PREDICT_ARGS);
+    else predict_kernel<false, false><<<grid, block, 0, s>>>(PREDICT_ARGS);
+#undef PREDICT_ARGS
 }
 
 // ---------------------------------------------------------------------------
@@ -210,12 +233,43 @@ __global__ void __launch_bounds__(256)
 pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ list, int max_count,
            const int32_t* __restrict__ d_count, const double* __restrict__ H13,
            const int32_t* __restrict__ off, const uint8_t* __restrict__ type, double* __restrict__ out, long ldo,
-           InnovArgs iv, DeferArgs da)
+           InnovArgs iv, DeferArgs da, GateList gl)
 {
     const int c = blockIdx.y;
-    const int count = d_count ? *d_count : max_count;
-    if (c >= count) return;
-    const int f = list[c];
+    int count, f;
+    if (CAN_DEFER && gl.flags) {
+        // list and count from the rescue flags: this workgroup's feature is the c-th flagged one
+        __shared__ int s_w[4], s_f;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int running = 0;
+        for (int base = 0; base < gl.L; base += 256) {
+            const int i = base + (int)threadIdx.x;
+            const bool flag = i < gl.L && gl.flags[i] != 0;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) s_w[wave] = __popcll(bal);
+            __syncthreads();
+            int before = running;
+            for (int w = 0; w < wave; ++w) before += s_w[w];
+            before += __popcll(bal & ((1ull << lane) - 1ull));
+            if (flag && before == c) s_f = i;
+            running += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            __syncthreads();
+        }
+        count = running;
+        if (blockIdx.x == 0 && c == 0 && threadIdx.x == 0) {
+            const int nblk = (2 * count + 63) / 64;
+            gl.sel[SEL_K_HI] = count;
+            gl.sel[SEL_NBLK_HI] = nblk;
+            if (nblk > gl.cap_blocks) gl.sel[SEL_CAP_FLAG] = 1;
+        }
+        if (c >= count) return;
+        f = s_f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) gl.list_out[c] = f;
+    } else {
+        count = d_count ? *d_count : max_count;
+        if (c >= count) return;
+        f = list[c];
+    }
     if (iv.sc && blockIdx.x == 0 && threadIdx.x == 1) {
         double sv, cv;
         sincos(iv.x[iv.ith[c]], &sv, &cv); iv.sc[4 * c] = sv; iv.sc[4 * c + 1] = cv;
@@ -287,14 +341,16 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count, const double* H13, const int32_t* off, const uint8_t* type,
                 double* out, long ldo, const double* S, const double* z, const double* h, const uint8_t* has_h,
-                double* wv, int32_t* status, const double* x, const int32_t* ith, const int32_t* iph, double* sc, const DeferArgs* defer)
+                double* wv, int32_t* status, const double* x, const int32_t* ith, const int32_t* iph, double* sc, const DeferArgs* defer,
+                const GateList* gl)
 {
     if (max_count <= 0) return;
     InnovArgs iv{S, z, h, has_h, wv, status, x, ith, iph, sc};
     DeferArgs da{}; if (defer) da = *defer;
+    GateList g{}; if (gl && defer) g = *gl;
     const dim3 grid(NP / 256 + (NP % 256 ? 1 : 0), max_count);
-    if (defer) pht_kernel<true><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da);
-    else pht_kernel<false><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da);
+    if (defer) pht_kernel<true><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da, g);
+    else pht_kernel<false><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -618,6 +674,7 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
         sel[SEL_NBLK_LI] = nblk;
         sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
         sel[SEL_LI_DEFER] = 0;                       // (an update stage that is re-run starts without a deferred covariance)
+        sel[SEL_K_HI] = 0; sel[SEL_NBLK_HI] = 0;     // written by the second P H^T (GateList); no such launch without matched features
         if (nblk > cap_blocks) sel[SEL_CAP_FLAG] = 1;   // launch sequence too short: re-run
     }
 }

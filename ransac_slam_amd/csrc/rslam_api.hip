@@ -590,22 +590,29 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     // (P_li may be deferred -- a rank <= 4 low-innovation update keeps Y1 and its Jnorm aside instead of streaming P: the readers
     //  of P_li between here and the HI pass form its entries themselves, kernels.h DeferArgs)
     DeferArgs da{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p, c->d_Gd.p};
+    // The gate nu' S^-1 nu < chi2 (:584-595) has no launch of its own: the prediction decides every feature's flag, the
+    // workgroups of the second P H^T find their feature and the count from the flags (kernels.h GateArgs / GateList)
+    static const bool gate_apart = getenv("RSLAM_GATE_APART") != nullptr;      // measurement: rescue_gate_kernel as a launch
+    const GateArgs ga{c->d_ic.p, c->d_li.p, c->d_z.p, c->cfg.chi2_gate, c->d_hi.p};
     launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
                    c->d_h2.p, c->d_hash2.p, nullptr, c->d_H13b.p, c->d_S2.p,
-                   c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr, &da);
-    launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
-                       cap_hi, c->d_hi.p, c->d_hilist.p, sel);
+                   c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr, &da, gate_apart ? nullptr : &ga);
+    if (gate_apart)
+        launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
+                           1 << 20, c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
+    // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
+    const GateList gl{c->d_hi.p, c->L, c->d_hilist.p, sel, 1 << 20};
+    if (c->RP > 0)
+        launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
+                   c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &da,
+                   gate_apart ? nullptr : &gl);
     if (!persistent) {
         int32_t nb = 0;
         HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_HI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         cap_hi = nb;
     }
-    // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
-    if (c->RP > 0)
-        launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
-                   c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &da);
     rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, cap_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
