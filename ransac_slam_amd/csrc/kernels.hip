@@ -238,22 +238,26 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
     const int c = blockIdx.y;
     int count, f;
     if (CAN_DEFER && gl.flags) {
-        // list and count from the rescue flags: this workgroup's feature is the c-th flagged one
-        __shared__ int s_w[4], s_f;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // list and count from the rescue flags: this workgroup's feature is the c-th flagged one.  Every wave scans all L flag
+        // bytes by itself -- eight loads in flight per round of 512 features, ballots, no LDS, no barrier (a workgroup-wide
+        // scan with two barriers per 256 features cost a dependent load per chunk: +47 us on the 24 000 workgroups of C5)
+        const int lane = threadIdx.x & 63;
         int running = 0;
-        for (int base = 0; base < gl.L; base += 256) {
-            const int i = base + (int)threadIdx.x;
-            const bool flag = i < gl.L && gl.flags[i] != 0;
-            const unsigned long long bal = __ballot(flag);
-            if (lane == 0) s_w[wave] = __popcll(bal);
-            __syncthreads();
-            int before = running;
-            for (int w = 0; w < wave; ++w) before += s_w[w];
-            before += __popcll(bal & ((1ull << lane) - 1ull));
-            if (flag && before == c) s_f = i;
-            running += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-            __syncthreads();
+        f = -1;
+        for (int base = 0; base < gl.L; base += 512) {
+            bool fl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = base + 64 * u + lane; fl[u] = i < gl.L && gl.flags[i] != 0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long bal = __ballot(fl[u]);
+                const int cnt = __popcll(bal);
+                if (f < 0 && running + cnt > c) {               // (uniform) the c-th flagged feature is one of these 64
+                    const bool me = fl[u] && __popcll(bal & ((1ull << lane) - 1ull)) == c - running;
+                    f = base + 64 * u + (__ffsll((unsigned long long)__ballot(me)) - 1);
+                }
+                running += cnt;
+            }
         }
         count = running;
         if (blockIdx.x == 0 && c == 0 && threadIdx.x == 0) {
@@ -263,7 +267,6 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
             if (nblk > gl.cap_blocks) gl.sel[SEL_CAP_FLAG] = 1;
         }
         if (c >= count) return;
-        f = s_f;
         if (blockIdx.x == 0 && threadIdx.x == 0) gl.list_out[c] = f;
     } else {
         count = d_count ? *d_count : max_count;

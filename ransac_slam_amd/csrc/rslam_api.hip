@@ -592,7 +592,10 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     DeferArgs da{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p, c->d_Gd.p};
     // The gate nu' S^-1 nu < chi2 (:584-595) has no launch of its own: the prediction decides every feature's flag, the
     // workgroups of the second P H^T find their feature and the count from the flags (kernels.h GateArgs / GateList)
-    static const bool gate_apart = getenv("RSLAM_GATE_APART") != nullptr;      // measurement: rescue_gate_kernel as a launch
+    // (large maps keep the gate as a launch: there the second P H^T has tens of thousands of workgroups that would each scan
+    //  the flags -- measured at C5, 1000 landmarks: 25 us per frame more than the 6 us launch)
+    static const bool gate_env = getenv("RSLAM_GATE_APART") != nullptr;        // measurement: rescue_gate_kernel as a launch
+    const bool gate_apart = gate_env || c->L > 512;
     const GateArgs ga{c->d_ic.p, c->d_li.p, c->d_z.p, c->cfg.chi2_gate, c->d_hi.p};
     launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
                    c->d_h2.p, c->d_hash2.p, nullptr, c->d_H13b.p, c->d_S2.p,
