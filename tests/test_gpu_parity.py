@@ -554,6 +554,25 @@ def test_large_system_route_against_oracle(hip, oracle_lib):
         g.close()
 
 
+@pytest.mark.parametrize("chi2", [1e-3, 0.05, 0.1, 0.3])
+def test_large_system_route_short_hi_sweeps(hip, oracle_lib, chi2):
+    """The route of the large systems with few rescued features (the gate's chi2 turned down): no HI inliers at all -- the
+    HI rank update is then a pass-through that still has to materialise the deferred low-innovation covariance --, one
+    diagonal block (no trailing pass), two (one narrow pass), three (a narrow / wide pair and nothing behind it)."""
+    fr = make_frame(L=500, H=60, seed=11)
+    cfg = default_config(compat=1, adaptive=0)
+    cfg.chi2_gate = chi2
+    o, g, r0, r1 = run_both(hip, oracle_lib, fr, cfg, structure=1)
+    assert g.debug_update_mode() == 0
+    check_frame(o, g, r0, r1)
+    n_li, n_hi = int(r1["li"].sum()), int(r1["hi"].sum())
+    assert 1 <= n_li <= 2
+    blocks = (2 * n_hi + 63) // 64
+    assert blocks == {1e-3: 0, 0.05: 1, 0.1: 2, 0.3: 3}[chi2], (n_hi, blocks)
+    assert g.counters()["sweep_reruns"] == 0
+    g.close()
+
+
 @pytest.mark.parametrize("compat", [1, 0])
 def test_c5_against_oracle_fixture(hip, compat):
     """BASELINE config C5 (1000 landmarks, n = 6013, 1000 hypotheses) against the oracle: tests/golden/c5/*.npz hold the
