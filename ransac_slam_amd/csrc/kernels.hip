@@ -6,7 +6,7 @@
 // K4  score_kernel          hypothesis x feature inlier scoring (wave ballot/popcount)
 // K5  best_mask_kernel      replay of the sequential best/adaptive-n_hyp scan, inlier set of the winner
 // K6  prepare_system_kernel stacked system [S; P*H^T; nu^T]
-// K8  chol_diag_kernel, sweep_step_kernel (large systems: panel_kernel + trail_diag_kernel)
+// K8  chol_diag_kernel, sweep_step_kernel (large systems: panel_kernel + trail_stream_kernel / trail_stream2_kernel)
 //                           blocked right-looking Cholesky sweep, one launch per block step
 // K9  xupdate_rows          x + Y u, quaternion normalisation, Jnorm (first workgroups of K10's launch)
 // K10 rank_update_kernel    P - Y Y^T with symmetrisation (MFMA, lower-triangle tile pairs)
@@ -1450,31 +1450,6 @@ panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     store_tile(lds, tile, ldA);
 }
 
-__device__ __forceinline__ void trail_tile(double* __restrict__ A, long ldA, int step, int nblk, int rp_blocks,
-                                           int i, int j, int skip_next_diag, double* lds)
-{
-    if (step >= nblk || j >= nblk || i < j) return;
-    if (skip_next_diag && i == step + 1 && j == step + 1) return;   // applied by the diagonal-block factorisation itself
-    if (!row_block_active(i, step, nblk, rp_blocks)) return;
-    const double* Ai = A + (long)i * 64 + (long)step * 64 * ldA;
-    const double* Aj = A + (long)j * 64 + (long)step * 64 * ldA;
-    double* C = A + (long)i * 64 + (long)j * 64 * ldA;
-    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
-    double cin[16];                                   // the tile to update: in flight under the product
-#pragma unroll
-    for (int q = 0; q < 16; ++q) cin[q] = C[row + (long)(g + 4 * q) * ldA];
-    TgAcc acc;
-    tg_zero(acc);
-    tile_gemm_nt(Ai, ldA, Aj, ldA, 64, lds, acc);
-    tg_acc_to_lds(acc, lds, 1.0);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = g + 4 * q;
-        C[row + (long)c * ldA] = cin[q] - lds[c * TS_LD + row];
-    }
-}
-
 // One launch per block step k of the sweep:
 //   workgroup 0      forms its own panel row X = A(k+1,k) Linv(k)^T, applies the step-k update to tile
 //                    (k+1,k+1) and factors it (cd_factor_block, pending = 2): the serial chain of the sweep;
@@ -1565,29 +1540,6 @@ sweep_step_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
     step_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, Linv + (long)step * 64 * 64, Yout, lds);
 }
 
-// Large systems (C5: 127 row blocks x 24 trailing columns): recomputing the panels in every tile would triple the
-// MFMA work of the sweep, so there the panel is solved once (panel_kernel, in place) and this launch holds the
-// trailing update of step k plus the factorisation of diagonal block k+1 (cd_factor_block, pending = 1).
-__global__ void __launch_bounds__(CD_THREADS)
-trail_diag_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-                  int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (blockIdx.x == 0) {
-        if (step + 1 >= rp_blocks) return;
-        CdPre pre;
-        cd_preload(pre, A, ldA, step + 1, Linv, 1);
-        if (step + 1 < sel[slot_nblk])
-            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, step + 1, sel, slot_k, Linv, status, 1, pre);
-        return;
-    }
-    const int nblk = sel[slot_nblk];
-    if (step + 1 >= nblk) return;                                 // no trailing matrix left
-    if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
-    const int b = blockIdx.x - 1;
-    trail_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, 1, lds);
-}
-
 // compile-time loop: an accumulator array must never be indexed dynamically (it would move to scratch)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -1600,13 +1552,13 @@ __device__ __forceinline__ void static_for(F&& f)
 
 // The trailing update as a stream (what large systems run).  The tiles of a pass, row-major over the active rows, are dealt
 // out in contiguous ranges to at most (compute units - 1) workgroups, and the two four-wave engines of a workgroup take
-// alternate tiles of its range: two tiles in flight per compute unit instead of one (trail_diag_kernel retires half of its
-// waves and, with the diagonal block's LDS, runs one workgroup per compute unit: 2.7 TB/s of tile traffic at C5), no
+// alternate tiles of its range: two tiles in flight per compute unit instead of one (the round-2 form, one workgroup per tile
+// with half of its waves retired and, with the diagonal block's LDS, one workgroup per compute unit, moved 2.7 TB/s at C5), no
 // workgroup launch / drain per tile, operands through the LDS-DMA engine of the rank update.  HBM-bound (64 KB per tile and
 // pass), so a pass applies TWO panels wherever the dependencies allow (launch_factor_sweep: block steps in pairs):
-//   narrow pass (NPAN = 1, one_col): panel k onto column block j_lo = k + 1 only -- and onto the diagonal tile after it
+//   narrow pass (trail_stream_kernel, one_col): panel k onto column block j_lo = k + 1 only -- and onto the diagonal tile after it
 //                (`extra`), which the NEXT diagonal workgroup needs complete but for its own panel;
-//   wide pass   (NPAN = 2): panels k, k + 1 onto every column block from j_lo = k + 2 on: K = 128 per tile and pass.
+//   wide pass   (trail_stream2_kernel): panels k, k + 1 onto every column block from j_lo = k + 2 on: K = 128 per tile and pass.
 // Workgroup 0 of either factors diagonal block `diag` = j_lo (cd_factor_block applies the panel in front of it itself).
 struct TrailPass { int p0, j_lo, one_col, extra; };
 
@@ -1628,7 +1580,6 @@ __device__ __forceinline__ void trail_decode(int t, const TrailPass& ps, int nS,
     }
 }
 
-template <int NPAN>
 __global__ void __launch_bounds__(CD_THREADS)
 trail_stream_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_t* __restrict__ sel, int slot_nblk,
                     int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
@@ -1676,13 +1627,8 @@ trail_stream_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_
         td_issue_chunk_w<0>(Xi, ldA, Xj, ldA, 0, Abuf[0], Bbuf[0], wave4);
         __syncthreads();                                          // (waits for this wave's transfers -- and its tile)
         td_read_frags(td_frag_ptr(Abuf[0], Bbuf[0], wave4), 0, a, b);
-        static_for<0, 2 * NPAN>([&](auto CC) {
-            constexpr int c = decltype(CC)::value, cur = c & 1, nxt = cur ^ 1;
-            if constexpr (c + 1 < 2 * NPAN)
-                td_compute_chunk_w<true, 0, 0>(Abuf[cur], Bbuf[cur], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, TG_KC * (c + 1), Abuf[nxt], Bbuf[nxt], wave4);
-            else
-                td_compute_chunk_w<false, 0, 0>(Abuf[cur], Bbuf[cur], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 0, Abuf[nxt], Bbuf[nxt], wave4);
-        });
+        td_compute_chunk_w<true, 0, 0>(Abuf[0], Bbuf[0], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, TG_KC, Abuf[1], Bbuf[1], wave4);
+        td_compute_chunk_w<false, 0, 0>(Abuf[1], Bbuf[1], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 0, Abuf[0], Bbuf[0], wave4);
         __syncthreads();                                          // every fragment read
         tg_acc_to_lds_w(acc, hbase, 1.0, wave4);                  // 64 x 65 staging over the first operand pair
         __syncthreads();
@@ -1805,7 +1751,7 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
     }
 }
 
-static_assert(TG_KC == 32, "trail_stream_kernel: a 64-column panel is two chunks");
+static_assert(TG_KC == 32, "trail_stream_kernel / trail_stream2_kernel: a 64-column panel is two chunks");
 static_assert(2 * TD_OPER_DOUBLES >= TS_DOUBLES, "trail_stream_kernel stages a tile over one operand pair");
 
 // ---------------------------------------------------------------------------
@@ -3186,11 +3132,7 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
@@ -3266,7 +3208,7 @@ bool sweep_fused_eligible(const SystemDims& d)
 }
 
 // One stream: diag(0), then ONE launch per block step (sweep_step_kernel); for large systems (more than 512 tile
-// workgroups at the first step) panel(k) + trail_diag(k) instead, see trail_diag_kernel.
+// workgroups at the first step) panel(k) + the trailing passes of trail_stream_kernel / trail_stream2_kernel instead.
 // (A two-stream lookahead variant and a three-kernels-per-step sequence existed in rounds 1-2 for measurement: the cross-stream
 // event dependencies cost more than the trailing kernels they hide -- C3 frame 0.68 ms against 0.52 ms single-stream.)
 // Returns the buffer whose rows [RP, RP + NP] hold Y and u^T afterwards: Ystore for the one-launch-per-step
@@ -3304,42 +3246,30 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
         // (steps is the update's exact block count here -- the host has read it: enqueue_update -- or an upper bound: the
         //  kernels deal out the tiles of the device-side count, the grids only bound the number of workgroups)
         if (steps <= 0) return A;
-        static const bool tiles = getenv("RSLAM_TRAIL_TILES") != nullptr;     // measurement: one workgroup per tile, one panel per pass
-        static const bool w1 = getenv("RSLAM_TRAIL_W1") != nullptr;           // measurement: the stream with one panel per pass
         const int cus = device_cus();
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
-        auto stream_pass = [&](int npan, const TrailPass& ps) {
+        auto stream_pass = [&](bool wide, const TrailPass& ps) {
             const long nS = steps - ps.j_lo, nP = row_blocks - rp_blocks;
             const long total = ps.one_col ? nS + nP + 1 : nS * (nS + 1) / 2 + nP * nS;
             long W = (total + 1) / 2;
             if (W > cus - 1) W = cus - 1;
             if (W < 1) W = 1;
-            static const bool lockstep = getenv("RSLAM_TRAIL_LOCKSTEP") != nullptr;      // measurement: both engines in the same phase
-            if (npan == 2 && !lockstep) trail_stream2_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+            if (wide) trail_stream2_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
                 A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
-            else if (npan == 2) trail_stream_kernel<2><<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
-                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
-            else trail_stream_kernel<1><<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+            else trail_stream_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
                 A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
         };
         int step = 0;
         while (step < steps) {
             panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
             if (step + 1 >= steps) break;
-            if (tiles || cus < 2) {
-                trail_diag_kernel<<<dim3(1 + row_blocks * (steps - step - 1)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
-                    A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
-                ++step;
-            } else if (w1) {
-                stream_pass(1, TrailPass{step, step + 1, 0, 0});
-                ++step;
-            } else if (step + 2 < steps) {
-                stream_pass(1, TrailPass{step, step + 1, 1, 1});          // panel k onto column k+1 (+ the next diagonal tile)
+            if (step + 2 < steps) {
+                stream_pass(false, TrailPass{step, step + 1, 1, 1});      // panel k onto column k+1 (+ the next diagonal tile)
                 panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step + 1, sel, slot_nblk, Linv, rp_blocks);
-                stream_pass(2, TrailPass{step, step + 2, 0, 0});          // panels k, k+1 onto everything from column k+2 on
+                stream_pass(true, TrailPass{step, step + 2, 0, 0});       // panels k, k+1 onto everything from column k+2 on
                 step += 2;
             } else {
-                stream_pass(1, TrailPass{step, step + 1, 1, 0});          // the last column
+                stream_pass(false, TrailPass{step, step + 1, 1, 0});      // the last column
                 ++step;
             }
         }
