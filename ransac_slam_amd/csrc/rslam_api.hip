@@ -474,7 +474,8 @@ static const int32_t* tile_order(rslam_ctx* c, int NP)
 {
     const int nT = NP / 64;
     if (nT <= 0) return nullptr;
-    if (nT > 48) return nullptr;         // measured: beyond ~3000 states the plain row-major order is 3 % faster
+    // (round 2 kept the plain row-major order beyond 48 tile rows -- 3 % faster with the K loop of the time; with the LDS-DMA
+    //  loop the XCD-aware order wins there too: C5 frame 2.353 -> 2.320 ms, PMC: the row-major pass fetched 4.2 GB per launch)
     if (c->tile_order_nT != nT) {
         std::vector<int32_t> order;
         make_rank_update_order(nT, order);
