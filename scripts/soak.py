@@ -6,7 +6,8 @@ from ransac_slam_amd import api, default_config
 from ransac_slam_amd.synth import make_frame
 compat = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
-fr = make_frame(L=300, H=1000, seed=2)
+L, H, seed = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (300, 1000, 2)
+fr = make_frame(L=L, H=H, seed=seed)
 ctx = api.RslamHip(default_config(compat=compat, adaptive=0))
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
 ctx.step_predict(); ctx.sync()
@@ -26,5 +27,5 @@ for b in range(frames // 100):
 r1 = ctx.fetch_results(want_P=True)
 ts = np.array(ts)
 same = np.array_equal(r0["x_new"], r1["x_new"]) and np.array_equal(r0["P_new"], r1["P_new"])
-print("compat", compat, "frames", frames, "ms/frame median %.4f p99 %.4f max %.4f" % (np.median(ts), np.percentile(ts, 99), ts.max()),
+print("L", L, "compat", compat, "frames", frames, "ms/frame median %.4f p99 %.4f max %.4f" % (np.median(ts), np.percentile(ts, 99), ts.max()),
       "counters", ctx.counters(), "bitwise stable", same)
