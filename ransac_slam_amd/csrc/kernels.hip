@@ -6,7 +6,7 @@
 // K4  score_kernel          hypothesis x feature inlier scoring (wave ballot/popcount)
 // K5  best_mask_kernel      replay of the sequential best/adaptive-n_hyp scan, inlier set of the winner
 // K6  prepare_system_kernel stacked system [S; P*H^T; nu^T]
-// K8  chol_diag_kernel, sweep_step_kernel (large systems: panel_kernel + trail_stream_kernel / trail_stream2_kernel)
+// K8  chol_diag_kernel, sweep_step_kernel (large systems: + panel_kernel, trail_stream2_kernel)
 //                           blocked right-looking Cholesky sweep, one launch per block step
 // K9  xupdate_rows          x + Y u, quaternion normalisation, Jnorm (first workgroups of K10's launch)
 // K10 rank_update_kernel    P - Y Y^T with symmetrisation (MFMA, lower-triangle tile pairs)
@@ -1290,7 +1290,9 @@ __device__ __forceinline__ void cd_preload(CdPre& pre, const double* __restrict_
 template <bool LOCAL = false>
 __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict__ A, long ldA, int step,
                                                 const int32_t* __restrict__ sel, int slot_k, double* __restrict__ Linv,
-                                                int32_t* __restrict__ status, int pending, const CdPre& pre)
+                                                int32_t* __restrict__ status, int pending, const CdPre& pre,
+                                                const double* __restrict__ Xsrc = nullptr /* pending == 1: the buffer (shape of A) that holds
+                                                                                              the solved panel; default A itself */)
 {
     // rows/columns at and beyond r = 2k are identity padding (prepare_system_kernel): the pivot
     // chain stops after the last real row, L and L^-1 are the identity there
@@ -1345,7 +1347,7 @@ __device__ __forceinline__ void cd_factor_block(CdShared& sh, double* __restrict
             // Lookahead: the trailing update of step-1 for THIS tile, A(k,k) -= X X^T with X = A(k,k-1)
             // (already solved by panel(step-1)), is applied by the T waves so that the trailing-update
             // kernel of the previous step can run elsewhere while this block is factored.
-            const double* Xg = A + (long)step * 64 + (long)(step - 1) * 64 * ldA;
+            const double* Xg = (Xsrc ? Xsrc : A) + (long)step * 64 + (long)(step - 1) * 64 * ldA;
             for (int c = g; c < 64; c += CD_THREADS / 64) sh.Lf[c * CD_LD + row] = Xg[row + (long)c * ldA];
         }
         if (t < 16) sh.flags[t] = 0;
@@ -1434,7 +1436,7 @@ __device__ __forceinline__ void store_tile(const double* Cs, double* C, long ldc
 
 __global__ void __launch_bounds__(256)
 panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
-             const double* __restrict__ Linv, int rp_blocks)
+             const double* __restrict__ Linv, int rp_blocks, double* __restrict__ out /* same shape as A; may be A itself */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int nblk = sel[slot_nblk];
@@ -1447,7 +1449,7 @@ panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
     tile_gemm_nt(tile, ldA, Linv + (long)step * 64 * 64, 64, 64, lds, acc);   // X * Linv^T
     tg_acc_to_lds(acc, lds, 1.0);
     __syncthreads();
-    store_tile(lds, tile, ldA);
+    store_tile(lds, out + (long)b * 64 + (long)step * 64 * ldA, ldA);
 }
 
 // One launch per block step k of the sweep:
@@ -1462,11 +1464,12 @@ panel_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restri
 // instead of panel launch + max(trailing, diagonal).  All workgroups have the diagonal block's shape
 // (CD_THREADS); the tile workgroups retire their surplus waves at once.
 __device__ __forceinline__ void step_tile(double* __restrict__ A, long ldA, int step, int nblk, int rp_blocks,
-                                          int i, int j, const double* __restrict__ Linv_k, double* __restrict__ Yout, double* lds)
+                                          int i, int j, const double* __restrict__ Linv_k, double* __restrict__ Yout, double* lds,
+                                          bool store_s_rows = false /* also the panel blocks of the S rows below k+1 (a wide pass reads them) */)
 {
     if (!row_block_active(i, step, nblk, rp_blocks)) return;
     const bool has_col = (j < nblk) && (i >= j) && !(i == step + 1 && j == step + 1);   // (k+1,k+1) belongs to workgroup 0
-    const bool store_y = (j == step + 1) && (i >= rp_blocks);
+    const bool store_y = (j == step + 1) && (i >= rp_blocks || (store_s_rows && i >= step + 2));
     if (!has_col && !store_y) return;
     double* bufA = lds;                               // A(i,k), then Y_i
     double* bufB = lds + 2 * TG_OPER_DOUBLES;         // Linv(k)
@@ -1522,7 +1525,8 @@ __device__ __forceinline__ void step_tile(double* __restrict__ A, long ldA, int 
 __global__ void __launch_bounds__(CD_THREADS)
 sweep_step_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __restrict__ sel, int slot_nblk,
                   int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, double* __restrict__ Yout,
-                  int32_t* __restrict__ status)
+                  int32_t* __restrict__ status, int narrow /* large systems: 0 every trailing column; 1 column k+1 only, its panel
+                  blocks stored for every row (grid 1 + row_blocks); 2 the same + the diagonal tile (k+2,k+2) (one workgroup more) */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (blockIdx.x == 0) {
@@ -1537,7 +1541,11 @@ sweep_step_kernel(double* __restrict__ A, long ldA, int step, const int32_t* __r
     if (step >= nblk) return;
     if (threadIdx.x >= 256) return;                               // before any barrier: the tile code is written for 4 waves
     const int b = blockIdx.x - 1;
-    step_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, Linv + (long)step * 64 * 64, Yout, lds);
+    if (narrow && b >= row_blocks) {                               // (narrow == 2) panel k onto the diagonal tile after the next one
+        step_tile(A, ldA, step, nblk, rp_blocks, step + 2, step + 2, Linv + (long)step * 64 * 64, Yout, lds);
+        return;
+    }
+    step_tile(A, ldA, step, nblk, rp_blocks, b % row_blocks, b / row_blocks + step + 1, Linv + (long)step * 64 * 64, Yout, lds, narrow != 0);
 }
 
 // compile-time loop: an accumulator array must never be indexed dynamically (it would move to scratch)
@@ -1550,26 +1558,22 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
-// The trailing update as a stream (what large systems run).  The tiles of a pass, row-major over the active rows, are dealt
-// out in contiguous ranges to at most (compute units - 1) workgroups, and the two four-wave engines of a workgroup take
-// alternate tiles of its range: two tiles in flight per compute unit instead of one (the round-2 form, one workgroup per tile
-// with half of its waves retired and, with the diagonal block's LDS, one workgroup per compute unit, moved 2.7 TB/s at C5), no
-// workgroup launch / drain per tile, operands through the LDS-DMA engine of the rank update.  HBM-bound (64 KB per tile and
-// pass), so a pass applies TWO panels wherever the dependencies allow (launch_factor_sweep: block steps in pairs):
-//   narrow pass (trail_stream_kernel, one_col): panel k onto column block j_lo = k + 1 only -- and onto the diagonal tile after it
-//                (`extra`), which the NEXT diagonal workgroup needs complete but for its own panel;
-//   wide pass   (trail_stream2_kernel): panels k, k + 1 onto every column block from j_lo = k + 2 on: K = 128 per tile and pass.
-// Workgroup 0 of either factors diagonal block `diag` = j_lo (cd_factor_block applies the panel in front of it itself).
-struct TrailPass { int p0, j_lo, one_col, extra; };
+// The trailing update of large systems: block steps in pairs.
+//   narrow pass: panel k onto column block k+1 only -- and onto the diagonal tile after it, which the NEXT diagonal workgroup
+//                needs complete but for its own panel.  This is sweep_step_kernel restricted to one column (narrow = 1, 2):
+//                every tile forms the two panel blocks it needs itself and stores its own for the wide pass, so the first
+//                step of a pair has no panel launch (launch_factor_sweep);
+//   wide pass:   panels k, k+1 onto every column block from j_lo = k+2 on, K = 128 per tile and pass, as a stream
+//                (trail_stream2_kernel): the tiles, row-major over the active rows, are dealt out in contiguous ranges to at most
+//                (compute units - 1) workgroups whose two four-wave engines take alternate tiles through the LDS-DMA engine of
+//                the rank update -- two tiles in flight per compute unit, no workgroup launch / drain per tile (the round-2 form,
+//                one workgroup per tile and step with half of its waves retired, moved 2.7 TB/s at C5).
+// Workgroup 0 of either factors the next diagonal block (cd_factor_block applies the panel in front of it itself).
+struct TrailPass { int p0, j_lo; };      // first panel block, first column block of the pass
 
-__device__ __forceinline__ void trail_decode(int t, const TrailPass& ps, int nS, int nP, int tri, int rp_blocks, int& i, int& j)
+__device__ __forceinline__ void trail_decode(int t, const TrailPass& ps, int nS, int tri, int rp_blocks, int& i, int& j)
 {
-    if (ps.one_col) {
-        j = ps.j_lo;
-        if (t < nS) i = ps.j_lo + t;
-        else if (t < nS + nP) i = rp_blocks + (t - nS);
-        else { i = ps.j_lo + 1; j = ps.j_lo + 1; }
-    } else if (t < tri) {                            // S rows: row r = i - j_lo holds the tiles j = j_lo .. i
+    if (t < tri) {                                   // S rows: row r = i - j_lo holds the tiles j = j_lo .. i
         int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while ((r + 1) * (r + 2) / 2 <= t) ++r;
         while (r * (r + 1) / 2 > t) --r;
@@ -1580,68 +1584,6 @@ __device__ __forceinline__ void trail_decode(int t, const TrailPass& ps, int nS,
     }
 }
 
-__global__ void __launch_bounds__(CD_THREADS)
-trail_stream_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_t* __restrict__ sel, int slot_nblk,
-                    int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (blockIdx.x == 0) {
-        if (ps.j_lo >= rp_blocks) return;
-        CdPre pre;
-        cd_preload(pre, A, ldA, ps.j_lo, Linv, 1);
-        if (ps.j_lo < sel[slot_nblk])
-            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, ps.j_lo, sel, slot_k, Linv, status, 1, pre);
-        return;
-    }
-    const int nblk = sel[slot_nblk];
-    if (ps.j_lo >= nblk) return;                                  // no trailing matrix left
-    const int nS = nblk - ps.j_lo, nP = row_blocks - rp_blocks, tri = nS * (nS + 1) / 2;
-    const int total = ps.one_col ? nS + nP + ((ps.extra && ps.j_lo + 1 < nblk) ? 1 : 0) : tri + nP * nS;
-    const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1;
-    const int per = (total + W - 1) / W;
-    const int t0 = w * per, t1 = min(total, t0 + per);
-    if (t0 >= t1) return;                                         // (uniform over the workgroup, before any barrier)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), e = wave >> 2, wave4 = wave & 3;
-    const int tid = threadIdx.x & 255, row = tid & 63, g = tid >> 6;
-    double* hbase = lds + (long)e * TD_LDS_DOUBLES;
-    double* const Abuf[2] = { hbase, hbase + 2 * TD_OPER_DOUBLES };
-    double* const Bbuf[2] = { hbase + TD_OPER_DOUBLES, hbase + 3 * TD_OPER_DOUBLES };
-    const unsigned lo = td_lane_offset(ldA);
-    for (int tt = t0; tt < t1; tt += 2) {
-        const int t = tt + e;
-        const bool have = t < t1 && t != 0;                       // tile 0 = (j_lo, j_lo): the diagonal workgroup's own
-        int i, j;
-        trail_decode(t < t1 ? t : tt, ps, nS, nP, tri, rp_blocks, i, j);   // (an engine without a tile runs its sibling's: reads only)
-        const double* Xi = A + 64L * i + (long)ps.p0 * 64 * ldA;
-        const double* Xj = A + 64L * j + (long)ps.p0 * 64 * ldA;
-        double* C = A + 64L * i + 64L * j * ldA;
-        double cin[16];
-        if (have) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) cin[q] = C[row + (long)(g + 4 * q) * ldA];
-        }
-        TgAcc acc;
-        tg_zero(acc);
-        double a[TG_MI];
-        BFrag b[TG_NI];
-        td_issue_chunk_w<0>(Xi, ldA, Xj, ldA, 0, Abuf[0], Bbuf[0], wave4);
-        __syncthreads();                                          // (waits for this wave's transfers -- and its tile)
-        td_read_frags(td_frag_ptr(Abuf[0], Bbuf[0], wave4), 0, a, b);
-        td_compute_chunk_w<true, 0, 0>(Abuf[0], Bbuf[0], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, TG_KC, Abuf[1], Bbuf[1], wave4);
-        td_compute_chunk_w<false, 0, 0>(Abuf[1], Bbuf[1], acc, a, b, Xi, ldA, lo, Xj, ldA, lo, 0, Abuf[0], Bbuf[0], wave4);
-        __syncthreads();                                          // every fragment read
-        tg_acc_to_lds_w(acc, hbase, 1.0, wave4);                  // 64 x 65 staging over the first operand pair
-        __syncthreads();
-        if (have) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = g + 4 * q;
-                C[row + (long)c * ldA] = cin[q] - hbase[c * TS_LD + row];
-            }
-        }
-        __syncthreads();                                          // staging read before the next tile's transfers land in it
-    }
-}
 // The wide pass (two panels, K = 128) with its two engines half a tile apart: while one engine runs the four chunks of a
 // tile, the other writes its previous tile back and fetches its next one, so the matrix pipes of the compute unit see one
 // engine's MFMAs at a time, back to back, instead of both engines' followed by both engines' memory phases (the lock-step
@@ -1653,7 +1595,8 @@ trail_stream_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_
 //  K = 128 tile is ~6.5 us of engine time: 40 TFLOP/s chip-wide against the 58 of the rank update's K = 1664 loop.)
 __global__ void __launch_bounds__(CD_THREADS)
 trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32_t* __restrict__ sel, int slot_nblk,
-                     int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status)
+                     int slot_k, int rp_blocks, int row_blocks, double* __restrict__ Linv, int32_t* __restrict__ status,
+                     const double* __restrict__ X /* the solved panels (shape of A) */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (blockIdx.x == 0) {
@@ -1661,7 +1604,7 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
         CdPre pre;
         cd_preload(pre, A, ldA, ps.j_lo, Linv, 1);
         if (ps.j_lo < sel[slot_nblk])
-            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, ps.j_lo, sel, slot_k, Linv, status, 1, pre);
+            cd_factor_block(*reinterpret_cast<CdShared*>(lds), A, ldA, ps.j_lo, sel, slot_k, Linv, status, 1, pre, X);
         return;
     }
     const int nblk = sel[slot_nblk];
@@ -1693,9 +1636,9 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
     auto prepare = [&](int r, double (&dst)[16], double* Ad, double* Bd, const double*& xi, const double*& xj, double*& c, bool& mine) {
         const int t = t0 + 2 * r + e;
         int i, j;
-        trail_decode(t, ps, nS, nP, tri, rp_blocks, i, j);
-        xi = A + 64L * i + (long)ps.p0 * 64 * ldA;
-        xj = A + 64L * j + (long)ps.p0 * 64 * ldA;
+        trail_decode(t, ps, nS, tri, rp_blocks, i, j);
+        xi = X + 64L * i + (long)ps.p0 * 64 * ldA;
+        xj = X + 64L * j + (long)ps.p0 * 64 * ldA;
         c = A + 64L * i + 64L * j * ldA;
         mine = t != 0;                                            // tile 0 = (j_lo, j_lo): the diagonal workgroup's own
         if (mine) {
@@ -1751,8 +1694,8 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
     }
 }
 
-static_assert(TG_KC == 32, "trail_stream_kernel / trail_stream2_kernel: a 64-column panel is two chunks");
-static_assert(2 * TD_OPER_DOUBLES >= TS_DOUBLES, "trail_stream_kernel stages a tile over one operand pair");
+static_assert(TG_KC == 32, "trail_stream2_kernel: a 64-column panel is two chunks");
+static_assert(2 * TD_OPER_DOUBLES >= TS_DOUBLES, "trail_stream2_kernel stages a tile over one operand pair");
 
 // ---------------------------------------------------------------------------
 // K8, persistent form: the whole factor sweep of one update in ONE launch (systems whose workgroups are all
@@ -3132,8 +3075,6 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CD_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
@@ -3208,11 +3149,10 @@ bool sweep_fused_eligible(const SystemDims& d)
 }
 
 // One stream: diag(0), then ONE launch per block step (sweep_step_kernel); for large systems (more than 512 tile
-// workgroups at the first step) panel(k) + the trailing passes of trail_stream_kernel / trail_stream2_kernel instead.
+// workgroups at the first step) block steps in pairs: narrow pass, panel, wide pass (trail_stream2_kernel).
 // (A two-stream lookahead variant and a three-kernels-per-step sequence existed in rounds 1-2 for measurement: the cross-stream
 // event dependencies cost more than the trailing kernels they hide -- C3 frame 0.68 ms against 0.52 ms single-stream.)
-// Returns the buffer whose rows [RP, RP + NP] hold Y and u^T afterwards: Ystore for the one-launch-per-step
-// sequence, A itself for the others.
+// Returns the buffer whose rows [RP, RP + NP] hold Y and u^T afterwards (Ystore on every route).
 double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
                             const int32_t* sel, int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
                             int32_t* status_sel, int32_t* flags, const SysSrc* src, const WorkerArgs* wk)
@@ -3242,44 +3182,48 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
         return Ystore;
     }
     if ((long)row_blocks * steps > 512) {
-        // large system: panel once per step; the trailing update as a stream, two panels per pass (trail_stream_kernel)
+        // large system: block steps in pairs -- narrow pass, panel, wide pass (see trail_stream2_kernel)
         // (steps is the update's exact block count here -- the host has read it: enqueue_update -- or an upper bound: the
         //  kernels deal out the tiles of the device-side count, the grids only bound the number of workgroups)
-        if (steps <= 0) return A;
+        if (steps <= 0) return Ystore;
         const int cus = device_cus();
         chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
-        auto stream_pass = [&](bool wide, const TrailPass& ps) {
+        auto wide_pass = [&](const TrailPass& ps, const double* X) {
             const long nS = steps - ps.j_lo, nP = row_blocks - rp_blocks;
-            const long total = ps.one_col ? nS + nP + 1 : nS * (nS + 1) / 2 + nP * nS;
+            const long total = nS * (nS + 1) / 2 + nP * nS;
             long W = (total + 1) / 2;
             if (W > cus - 1) W = cus - 1;
             if (W < 1) W = 1;
-            if (wide) trail_stream2_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
-                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
-            else trail_stream_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
-                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel);
+            trail_stream2_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+                A, d.ldA, ps, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel, X);
         };
+        // The panel of the first step of a pair has no launch of its own: the narrow pass forms the two panel blocks each of its
+        // tiles needs itself (sweep_step_kernel restricted to column k+1: three 64^3 products per tile instead of one, ~120
+        // tiles under an 18 us pivot chain), the diagonal workgroup its own (cd_factor_block, pending = 2), and stores the
+        // blocks the wide pass will read into the second buffer -- the raw column k of A stays as it is, so nobody races.
+        // Every solved panel therefore lives in Ystore (the panel launch of the second step writes there too).
         int step = 0;
         while (step < steps) {
-            panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks);
-            if (step + 1 >= steps) break;
-            if (step + 2 < steps) {
-                stream_pass(false, TrailPass{step, step + 1, 1, 1});      // panel k onto column k+1 (+ the next diagonal tile)
-                panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step + 1, sel, slot_nblk, Linv, rp_blocks);
-                stream_pass(true, TrailPass{step, step + 2, 0, 0});       // panels k, k+1 onto everything from column k+2 on
-                step += 2;
-            } else {
-                stream_pass(false, TrailPass{step, step + 1, 1, 0});      // the last column
-                ++step;
+            if (step + 1 >= steps) {                                  // the last column's panel: Y and u^T of that block
+                panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step, sel, slot_nblk, Linv, rp_blocks, Ystore);
+                break;
             }
+            const bool pair = step + 2 < steps;
+            sweep_step_kernel<<<dim3(1 + row_blocks + (pair ? 1 : 0)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
+                A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel, pair ? 2 : 1);
+            if (!pair) { ++step; continue; }
+            panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step + 1, sel, slot_nblk, Linv, rp_blocks, Ystore);
+            wide_pass(TrailPass{step, step + 2}, Ystore);                     // panels k, k+1 onto everything from column k+2 on
+            step += 2;
         }
+        return Ystore;
         return A;
     }
     if (steps <= 0) return Ystore;
     chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
     for (int step = 0; step < steps; ++step)     // column jj = 0 also stores the panel, so the last step still has one
         sweep_step_kernel<<<dim3(1 + row_blocks * (steps - step)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
-            A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel);
+            A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel, 0);
     return Ystore;
 }
 
