@@ -1611,7 +1611,17 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
     if (ps.j_lo >= nblk) return;
     const int nS = nblk - ps.j_lo, nP = row_blocks - rp_blocks, tri = nS * (nS + 1) / 2;
     const int total = tri + nP * nS;
-    const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1;
+    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness): the ranges are handed out so that the
+    // workgroups that share an L2 own CONSECUTIVE ranges -- a dozen neighbouring rows whose X_i panels and the pass's X_j panels
+    // fit that L2 -- instead of every eighth one
+    const int W = (int)gridDim.x - 1;
+    int w;
+    {
+        const int bx = (int)blockIdx.x, g = bx & 7;              // bx = 1 .. W
+        int off = 0;                                              // workgroups of the XCD groups in front of g (order 1, 2, .., 7, 0)
+        for (int h = 1; h < 8 && (g == 0 || h < g); ++h) off += (W >= h) ? (W - h) / 8 + 1 : 0;
+        w = off + (g == 0 ? (bx >> 3) - 1 : (bx >> 3));
+    }
     const int per = (total + W - 1) / W;
     const int t0 = w * per, t1 = min(total, t0 + per);
     if (t0 >= t1) return;                                         // (uniform over the workgroup, before any barrier)
