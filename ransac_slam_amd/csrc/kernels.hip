@@ -1588,8 +1588,9 @@ __device__ __forceinline__ void trail_decode(int t, const TrailPass& ps, int nS,
 // tile, the other writes its previous tile back and fetches its next one, so the matrix pipes of the compute unit see one
 // engine's MFMAs at a time, back to back, instead of both engines' followed by both engines' memory phases (the lock-step
 // form above: 35 TFLOP/s at C5's first pass).  A slot = the three chunk barriers of the computing engine; the other engine
-// matches them: (1) its accumulators are staged in the operand pair its tile finished with two chunks ago, (2) a bare
-// s_barrier -- its stores, the next tile and that tile's first operand chunk stay in flight -- and (3) the wait for them.
+// matches them: the values of its next tile are requested first of all; (1) its accumulators are staged in the operand pair its
+// tile finished with two chunks ago (an LDS-only barrier: the requests stay in flight), (2) a bare s_barrier -- its stores,
+// the next tile and that tile's first operand chunk stay in flight -- and (3) the wait for them.
 // (Measured the same, C5 frame 2.440 ms against 2.441: both engines in step as one software pipeline -- the last chunk of a
 //  tile fetching the first chunk of the next, the write-back behind a bare s_barrier -- at 248 VGPRs; not kept.  Either way a
 //  K = 128 tile is ~6.5 us of engine time: 40 TFLOP/s chip-wide against the 58 of the rank update's K = 1664 loop.)
@@ -1643,7 +1644,8 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
     TgAcc acc;
     tg_zero(acc);
     // fetch tile r of this engine: its values into `dst`, its first operand chunk into (Ad, Bd)
-    auto prepare = [&](int r, double (&dst)[16], double* Ad, double* Bd, const double*& xi, const double*& xj, double*& c, bool& mine) {
+    // tile r of this engine: where it is, and its values into `dst`
+    auto fetch_tile = [&](int r, double (&dst)[16], const double*& xi, const double*& xj, double*& c, bool& mine) {
         const int t = t0 + 2 * r + e;
         int i, j;
         trail_decode(t, ps, nS, tri, rp_blocks, i, j);
@@ -1655,9 +1657,11 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
 #pragma unroll
             for (int q = 0; q < 16; ++q) dst[q] = c[row + (long)(g + 4 * q) * ldA];
         }
-        td_issue_chunk_w<0>(xi, ldA, xj, ldA, 0, Ad, Bd, wave4);
     };
-    if (e == 0) prepare(0, cin, Ac, Bc, Xi, Xj, C, own);          // (n >= 1: engine 0 always has a tile)
+    if (e == 0) {                                                 // (n >= 1: engine 0 always has a tile)
+        fetch_tile(0, cin, Xi, Xj, C, own);
+        td_issue_chunk_w<0>(Xi, ldA, Xj, ldA, 0, Ac, Bc, wave4);
+    }
     __syncthreads();
     for (int s = 0; s <= n; ++s) {
         const int r = s >> 1;
@@ -1680,11 +1684,13 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
             const bool finish = s >= 1 && ((s - 1) >> 1) < n_mine;
             const int rn = (s + 1) >> 1;
             const bool more = rn < n_mine;
-            if (finish) tg_acc_to_lds_w(acc, Ac, 1.0, wave4);     // (Ac, Bc): read for the last time two chunks ago
-            __syncthreads();                                      // (1) staged; every wave of the engine is through its last chunk
             double* Cw = C;
             const bool ownw = own;
-            if (more) prepare(rn, cnx, An, Bn, Xi, Xj, C, own);
+            if (more) fetch_tile(rn, cnx, Xi, Xj, C, own);        // the next tile's values: requested first, they have the whole slot
+            if (finish) tg_acc_to_lds_w(acc, Ac, 1.0, wave4);     // (Ac, Bc): read for the last time two chunks ago
+            // (1) staged; every wave of the engine is through its last chunk.  Bare: the loads above stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (more) td_issue_chunk_w<0>(Xi, ldA, Xj, ldA, 0, An, Bn, wave4);
             if (finish && ownw) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
