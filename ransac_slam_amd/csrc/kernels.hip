@@ -1643,7 +1643,6 @@ trail_stream2_kernel(double* __restrict__ A, long ldA, TrailPass ps, const int32
     double cin[16], cnx[16];
     TgAcc acc;
     tg_zero(acc);
-    // fetch tile r of this engine: its values into `dst`, its first operand chunk into (Ad, Bd)
     // tile r of this engine: where it is, and its values into `dst`
     auto fetch_tile = [&](int r, double (&dst)[16], const double*& xi, const double*& xj, double*& c, bool& mine) {
         const int t = t0 + 2 * r + e;
