@@ -89,9 +89,9 @@ def cpu_baseline(frame, cfg, sample_iters, seed):
     _, vis, _ = o.predict(frame.types, frame.x_pred, frame.P_pred)
     t1 = time.perf_counter()
     ic = frame.ic & vis
-    o.ransac_only(frame.z, ic, frame.draws, max_iters=sample_iters)
+    rr = o.ransac_only(frame.z, ic, frame.draws, max_iters=sample_iters)
     t2 = time.perf_counter()
-    o.finish_update()
+    fu = o.finish_update()
     t3 = time.perf_counter()
     H, m = len(frame.draws), int(ic.sum())
     iters_done = min(sample_iters, H)
@@ -127,7 +127,12 @@ def cpu_baseline(frame, cfg, sample_iters, seed):
                                           timeout=120, check=True).stdout.strip().splitlines()[-1])
         except Exception:                              # a baseline extra: never fail the bench line over it
             omp_ms, omp_threads = None, None
-    return dict(value=H * m / est_frame_s, unit="hypotheses*features/s", cores=1, kind="port",
+    # what the reference-structure oracle decided and computed on this very frame (all H iterations run): held against the
+    # timed context's results by parity_in_run()
+    full = (iters_done == H)
+    oracle_result = dict(li=fu["li"], hi=fu["hi"], x_new=fu["x_new"], best_hyp=rr["best_hyp"], best_support=rr["best_support"],
+                         hyps_evaluated=rr["hyps_evaluated"]) if full else None
+    return oracle_result, dict(value=H * m / est_frame_s, unit="hypotheses*features/s", cores=1, kind="port",
                 optimised_cpu_all_cores_ms_per_frame=omp_ms, optimised_cpu_all_cores_threads=omp_threads,
                 optimised_cpu_ms_per_frame=(t5 - t4) * 1e3,
                 optimised_cpu_note="oracle structure=1 (structured H, cached hypotheses), 1 thread; not the reference's structure",
@@ -137,6 +142,38 @@ def cpu_baseline(frame, cfg, sample_iters, seed):
                         f"estimated {est_frame_s:.1f} s/frame; note the RANSAC update flags of the sample differ "
                         f"from the full run only in fixed mode"),
                 est_ms_per_frame=est_frame_s * 1e3, host_cpus=os.cpu_count(), cpu_model=cpu_model())
+
+
+def oracle_frame_result(frame, cfg, ic):
+    """the structured oracle (same arithmetic, structural zeros of H skipped; ~2 s at C3) on a frame: the checker of parity_in_run
+    for the workloads whose reference-structure oracle run is not part of the line"""
+    from oracle import pyoracle as po          # checker only
+    o = po.Oracle(cfg, structure=1)
+    o.predict(frame.types, frame.x_pred, frame.P_pred)
+    return o.ransac_update(frame.z, ic, frame.draws)
+
+
+def parity_in_run(name, timed, ref):
+    """The frame the timed region replayed, against the oracle on the same frame: decisions bit-exact
+    (Tracking.cpp:507-529: winner, support, evaluated count; the LI / HI sets), x_k_k to 1e-9 (ExtendKF.cpp:606).
+    `timed` = rslam_fetch_results of the timed context AFTER the timed region (the last replayed frame's outputs)."""
+    out = {"workload": name}
+    ok = True
+    for k in ("best_hyp", "best_support", "hyps_evaluated"):
+        out[k] = [int(timed[k]), int(ref[k])]
+        ok = ok and int(timed[k]) == int(ref[k])
+    for k in ("li", "hi"):
+        same = bool(np.array_equal(np.asarray(timed[k], np.uint8), np.asarray(ref[k], np.uint8)))
+        out[k + "_identical"] = same
+        out["n_" + k] = int(np.asarray(ref[k]).sum())
+        ok = ok and same
+    scale = max(1.0, float(np.max(np.abs(ref["x_new"]))))
+    dx = float(np.max(np.abs(np.asarray(timed["x_new"]) - np.asarray(ref["x_new"]))))
+    out["x_new_max_abs_diff"] = dx
+    out["x_new_tol"] = 1e-9 * scale
+    ok = ok and dx <= 1e-9 * scale
+    out["ok"] = bool(ok)
+    return out
 
 
 def visible_ic(ctx, frame):
@@ -222,6 +259,7 @@ class Runner:
 
     def result(self):
         res = self.ctx.fetch_results(want_P=False)
+        self.last = res                   # (li / hi / x_new of the last replayed frame: parity_in_run)
         return {k: int(res[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")}
 
 
@@ -311,12 +349,30 @@ def main():
     backend = os.environ.get("RSLAM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        torch.cuda.set_stream(torch.cuda.Stream())     # kernels and the all-gather share this side stream
+        # Fail fast and loudly: a rank that cannot join (or whose first collective errors) must end the job with a message,
+        # not leave the others sitting in a barrier until the driver's clock runs out.
+        tmo = datetime.timedelta(seconds=int(os.environ.get("RSLAM_BENCH_COLL_TIMEOUT_S", "120")))
+        try:
+            if backend == "nccl":
+                os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+            torch.cuda.set_stream(torch.cuda.Stream())     # kernels and the all-gather share this side stream
+            probe_in = torch.full((4,), rank, dtype=torch.int32, device="cuda")
+            probe_out = torch.empty((4 * world,), dtype=torch.int32, device="cuda")
+            dist.all_gather_into_tensor(probe_out, probe_in)       # the collective of the data path, once, checked
+            torch.cuda.current_stream().synchronize()
+            expect = torch.arange(world, dtype=torch.int32).repeat_interleave(4)
+            if not torch.equal(probe_out.cpu(), expect):
+                raise RuntimeError("all-gather probe returned %s" % probe_out.cpu().tolist())
+        except Exception as e:                              # noqa: BLE001 -- whatever it was, say which rank and stop everybody
+            sys.stderr.write("bench.py: rank %d/%d (device %d, backend %s) could not set up the collective: %r\n"
+                             % (rank, world, local_rank, backend, e))
+            sys.stderr.flush()
+            os._exit(3)                                     # (not sys.exit: a hung communicator would block interpreter shutdown)
 
     wl = WORKLOADS[args.workload]
     use_graph = not args.no_graph
@@ -324,7 +380,8 @@ def main():
     ctx, frame, ic, m = run.ctx, run.frame, run.ic, run.m
     H_total, H_local = run.H_total, run.H_local
     elapsed = run.timed(args.steps, args.warmup)
-    res = ctx.fetch_results(want_P=False)
+    res = ctx.fetch_results(want_P=False)         # outputs of the LAST frame of the timed region (checked below: parity_in_run)
+    parity = []
 
     def config_of(r, wl_):
         return {"workload": wl_["name"], "landmarks": wl_["L"], "state_dim": int(r.frame.n),
@@ -397,6 +454,8 @@ def main():
         if rank == 0:
             out["compat0"] = {"ms_per_step": e2 / args.steps * 1e3, "value": alt.H_total * alt.m * args.steps / e2,
                               "result": alt.result(), "config": config_of(alt, wl)}
+            if world == 1 and not args.no_cpu_baseline:
+                parity.append(parity_in_run("compat0", alt.last, oracle_frame_result(alt.frame, alt.cfg, alt.ic)))
             if world == 1:
                 out["compat0"]["sequence"] = sequence_run(alt)
         alt.ctx.close()
@@ -435,7 +494,7 @@ def main():
                      "stage_us": {kk: round(vv, 1) for kk, vv in acc5.items()}, "outliers": out5,
                      "rank_update": {"launch_us": us5, "rank_r": rr5, "achieved_TFLOPs": f5 / (us5 * 1e-6) * 1e-12 if us5 > 0 else 0.0,
                                      "frac_of_fp64_mfma_peak": f5 / (us5 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if us5 > 0 else 0.0},
-                     "update_mode": c5.ctx.debug_update_mode(),
+                     "update_mode": c5.ctx.update_mode(),
                      "note": "too large for the persistent sweep (508 strips > CUs): launch-per-step sweep + stand-alone rank update"}
             if cm == args.compat:
                 out["c5"].update(line5)
@@ -455,7 +514,7 @@ def main():
         n = int(frame.n)
         res_e = ctx.fetch_results(want_P=False)
         k_li, k_hi = res_e["n_li"], res_e["n_hi"]
-        mode = ctx.debug_update_mode()
+        mode = ctx.update_mode()
         out["update_mode"] = {0: "launch-per-step sweep + stand-alone rank update", 1: "persistent sweep + stand-alone rank update",
                               2: "persistent sweep with the x / covariance update inside its launch"}[mode]
         r = 2 * k_hi
@@ -491,7 +550,13 @@ def main():
                                        "stream, mean of %d eager frames).  The launch is paced by the serial pivot chain of ONE workgroup "
                                        "(r dependent pivots); the rank update runs under it on the compute units the sweep leaves idle" % nrep}
             try:
-                st = ctx.debug_sweep_stamps()
+                # (time stamps exist in the diagnostic variant of the library only: one stamped frame on a context of its own)
+                dctx = RslamHip(run.cfg, device=local_rank, debug=True)
+                dctx.load_frame(frame.types, frame.x_pred, frame.P_pred, frame.z, ic, frame.draws)
+                for _ in range(3):
+                    dctx.step_frame(False); dctx.sync()
+                st = dctx.debug_sweep_stamps()
+                dctx.close()
                 ends = st[0, :, 5][st[0, :, 5] > 0]
                 if len(ends) and st[5, 0, 4] > 0:
                     out["roofline"]["exposed_tail_us"] = float(st[5, 0, 4] - ends.max()) / 100.0
@@ -566,10 +631,23 @@ def main():
         # widened rows of SURVEY 8(f), timed beside their oracle restatements (host calls incl. transfers + sync)
         out["widened_rows"] = widened_rows(ctx, frame)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(frame, default_config(compat=args.compat, adaptive=0), args.cpu_sample_iters, wl["seed"])
+        ref, out["cpu_baseline"] = cpu_baseline(frame, default_config(compat=args.compat, adaptive=0), args.cpu_sample_iters, wl["seed"])
+        # ---- the timed frame IS the right frame: its outputs against what the reference-structure oracle (the cpu_baseline leg
+        # above, outside every timed region) computed on the same inputs
+        if ref is None:                                     # a shortened CPU sample: the structured oracle checks instead
+            ref = oracle_frame_result(frame, default_config(compat=args.compat, adaptive=0), ic)
+        parity.insert(0, parity_in_run("headline (%s, compat %d)" % (args.workload, args.compat), res, ref))
+        out["parity_in_run"] = {"checked": True, "ok": all(p["ok"] for p in parity), "frames": parity,
+                                "note": "outputs of the last frame of each timed region (rslam_fetch_results after the fence) vs the "
+                                        "oracle on the same inputs: best_hyp / best_support / hyps_evaluated / LI / HI sets bit-exact, "
+                                        "x_k_k within 1e-9 * max(1, |x|); the oracle runs outside the timed regions"}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
+    if rank == 0 and "parity_in_run" in out and not out["parity_in_run"]["ok"]:
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit("bench.py: the timed frame's results differ from the oracle's (parity_in_run)")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

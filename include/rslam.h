@@ -254,7 +254,9 @@ int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t h
  * consensus scan on the gathered list and applies both updates (phase 1): bit-identical posteriors on all ranks, no
  * covariance broadcast.  nccl_comm is the caller's ncclComm_t (rccl.h) of `world` ranks; NULL is allowed for
  * world == 1 (no collective).  RCCL is bound at the first call (the librccl.so.1 already in the process, else the
- * system one): librslam_hip.so itself does not depend on it.  Every rank must have loaded the same frame
+ * system one): librslam_hip.so itself does not depend on it; before the first collective of a communicator its size and
+ * this rank's index in it are checked against `world` / `rank` (ncclCommCount, ncclCommUserRank: RSLAM_ERR_COMM on a
+ * mismatch instead of a hung all-gather).  Every rank must have loaded the same frame
  * (rslam_load_frame / rslam_load_measurements).  Stream-ordered like rslam_step_frame: results via rslam_sync and
  * rslam_fetch_results. */
 int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph);
@@ -266,6 +268,13 @@ int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
  * next 64 frames (doubling while the timeouts keep coming), or because the Jnorm hand-over of the stand-alone rank update
  * timed out (re-run with the x-update riders dispatched first). */
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
+/* How the update stage of the loaded frame shape runs: 0 = launch-per-step factor sweep + stand-alone rank update (systems too
+ * large for one persistent launch, or the fallback after a timed-out hand-over), 1 = persistent sweep + stand-alone rank
+ * update, 2 = persistent sweep with the x / covariance update inside its launch (ExtendKF.cpp:602-609 in one kernel). */
+int rslam_update_mode(rslam_ctx* ctx);
+/* The raw device-side code of the last bounded wait that ran out (0: none): which hand-over it was (rslam_sync folds all of
+ * them into RSLAM_ERR_HIP or recovers by re-running the update stage, see rslam_get_counters). */
+int rslam_last_raw_status(rslam_ctx* ctx);
 
 /* Block until the stream is idle; returns the device-side status of the
  * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...).

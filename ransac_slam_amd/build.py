@@ -1,32 +1,77 @@
-"""Builds librslam_hip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950."""
+"""Builds the C-ABI library (HIP kernels + host logic) in-tree with hipcc for gfx950.
+
+Two variants of the same sources:
+  librslam_hip.so      the product: exports exactly what include/rslam.h declares
+  librslam_hip_dbg.so  -DRSLAM_DEBUG: the same kernels plus the diagnostic / fault-injection entry points
+                       (rslam_debug_*), the time-stamp buffers and the RSLAM_* measurement switches read from the
+                       environment.  Tests and scripts that inject faults or read stamps load this one; nothing of it
+                       is reachable from the product library.
+Every source is compiled to an object of its own (in parallel: kernels.hip takes ~2 minutes, the rest seconds), so a
+change of the host logic does not recompile the kernels.
+"""
+import concurrent.futures
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librslam_hip.so")
+LIB_DEBUG = os.path.join(HERE, "librslam_hip_dbg.so")
 SOURCES = ["kernels.hip", "map_kernels.hip", "match_kernels.hip", "rslam_api.hip"]
 HEADERS = ["kernels.h", "tile_gemm.h", "camera_model.h", os.path.join("..", "..", "include", "rslam.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS)
+
+
+def _obj_path(src, debug):
+    return os.path.join(OBJ, ("dbg_" if debug else "rel_") + os.path.splitext(src)[0] + ".o")
+
+
+def _obj_stale(src, debug):
+    o = _obj_path(src, debug)
+    if not os.path.exists(o):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(o)
+    return os.path.getmtime(os.path.join(CSRC, src)) > t or _newest_header() > t
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
+def _compile(job):
+    src, debug, extra = job
+    cmd = [_hipcc()] + FLAGS + (["-DRSLAM_DEBUG"] if debug else []) + list(extra) + \
+          ["-c", os.path.join(CSRC, src), "-o", _obj_path(src, debug)]
     subprocess.check_call(cmd)
-    return LIB
+    return " ".join(cmd)
+
+
+def build(force=False, verbose=False, debug=None, extra_flags=()):
+    """debug: False = the product library, True = the diagnostic variant, None = both.  Returns the product library's path
+    (the diagnostic one's when debug is True)."""
+    variants = [False, True] if debug is None else [bool(debug)]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = [(src, dbg, tuple(extra_flags)) for dbg in variants for src in SOURCES if force or extra_flags or _obj_stale(src, dbg)]
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            for line in ex.map(_compile, jobs):
+                if verbose:
+                    print(line)
+    for dbg in variants:
+        lib = LIB_DEBUG if dbg else LIB
+        objs = [_obj_path(src, dbg) for src in SOURCES]
+        if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    return LIB_DEBUG if debug else LIB
 
 
 HOST_DIR = os.path.join(HERE, "host")

@@ -12,8 +12,7 @@ namespace rslam {
 enum SelSlot {
     SEL_BEST_HYP = 0, SEL_BEST_SUPPORT = 1, SEL_HYPS_EVALUATED = 2,
     SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7, SEL_XU_FLAG = 8,
-    SEL_CAP_FLAG = 9,        // != 0: the captured launch sequence of a factor sweep was shorter than the inlier count
-                             // needs; the host re-runs the update stage with the full-length sequence
+    SEL_UNUSED9 = 9,
     SEL_STATUS_FRONT = 10,   // status of the prediction / scoring stage (kept when only the update stage is re-run)
     SEL_STICKY = 11,         // smallest status of the frames whose status word the next frame's reset has overwritten unread
     SEL_LI_DEFER = 12,       // != 0: the covariance of the (rank <= 4) low-innovation update has not been written: it is
@@ -41,7 +40,7 @@ struct DeferArgs {
 // second P H^T finds its feature -- the c-th flagged one -- and the count from the L flag bytes itself (GateList: a ballot scan,
 // two barriers per 256 features); its first workgroups write the ordered list and the counts the HI sweep reads.
 struct GateArgs { const uint8_t* ic; const uint8_t* li; const double* z; double chi2; uint8_t* hi; };
-struct GateList { const uint8_t* flags; int L; int32_t* list_out; int32_t* sel; int cap_blocks; };
+struct GateList { const uint8_t* flags; int L; int32_t* list_out; int32_t* sel; };
 
 struct ScoreTables {          // per matched feature (rank j in feature order), m entries each
     const int32_t* feat;      // feature index
@@ -88,11 +87,11 @@ void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos
 // scatter its mask to li[], build list/count
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
-                      const int32_t* pos, double threshold, int L, int cap_blocks, int32_t* sel, uint8_t* li,
+                      const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
                       int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init);
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
-                        const double* S, const double* z, const double* h, double chi2, int cap_blocks,
+                        const double* S, const double* z, const double* h, double chi2,
                         uint8_t* hi, int32_t* list, int32_t* sel);
 
 struct SystemDims { int n, NP, RP, ldA; };   // stacked matrix A: rows [0,RP) S | [RP,RP+NP) W | RP+NP: nu^T (+63 pad)
@@ -118,8 +117,10 @@ struct WorkerArgs {
     int32_t* defer_flag; double* Y1; long ldy1; const double* Ppred; const double* T_li;
 };
 bool sweep_fused_eligible(const SystemDims& d);            // enough idle compute units for every tile pair of P
-void set_sweep_exp_mask(int mask);     // -1 = environment (RSLAM_SWEEP_EXP); diagnostics and fault injection
-int sweep_exp_mask();
+#if defined(RSLAM_DEBUG)
+void set_sweep_exp_mask(int mask);     // -1 = environment (RSLAM_SWEEP_EXP); diagnostics and fault injection (diagnostic variant only)
+#endif
+int sweep_exp_mask();                  // always 0 in the product build
 // What the persistent sweep builds its stacked system [S; P H^T; nu^T] from (it has no prepare_system pass): the
 // arguments of launch_prepare_system.  Wsrc != nullptr: P H^T columns come from the matched-feature matrix (LI pass),
 // else they are already in rows [RP, RP+NP) of A (HI pass: launch_pht wrote them there).
@@ -129,7 +130,7 @@ struct SysSrc {
 };   // the whole sweep in one launch (no dependence on the previous frame's counts)
 // returns the buffer (A or Ystore, same shape) whose rows [RP, RP + NP] hold Y and u^T afterwards
 double* launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel,
-                            int slot_k, int slot_nblk, int cap_blocks, double* A, double* Ystore, double* Linv,
+                            int slot_k, int slot_nblk, int host_blocks /* launch-per-step route: the update's block count as the host has read it */, double* A, double* Ystore, double* Linv,
                             int32_t* status_sel, int32_t* flags /* 2 * SWEEP_FLAG_INTS zeroed ints, or nullptr: never the persistent sweep */,
                             const SysSrc* src /* with flags: the sweep assembles the system itself (no launch_prepare_system) */,
                             const WorkerArgs* wk = nullptr /* persistent sweep only: x and covariance update inside the launch */);

@@ -204,7 +204,9 @@ void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double
     DeferArgs da{}; if (defer) da = *defer;
     GateArgs ga{}; if (gate) ga = *gate;
     if (L <= 0) {
-        if (sel_reset) (void)hipMemsetAsync(sel_reset, 0, sizeof(int32_t) * SEL_COUNT, s);
+        // an empty map: only the frame scalars are reset -- by the kernel itself (one workgroup, no feature), so that a status
+        // nobody has read is folded into the sticky slot here too
+        if (sel_reset) predict_kernel<false, false><<<dim3(1), dim3(128), 0, s>>>(cam, x, P, NP, 0, type, off, h_in, has_h_in, h, has_h, vis, H13, S, radd, sel_reset, da, ga);
         return;
     }
     const dim3 grid((L + 3) / 4), block(128);
@@ -264,7 +266,6 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
             const int nblk = (2 * count + 63) / 64;
             gl.sel[SEL_K_HI] = count;
             gl.sel[SEL_NBLK_HI] = nblk;
-            if (nblk > gl.cap_blocks) gl.sel[SEL_CAP_FLAG] = 1;
         }
         if (c >= count) return;
         if (blockIdx.x == 0 && threadIdx.x == 0) gl.list_out[c] = f;
@@ -645,7 +646,7 @@ __device__ __forceinline__ int block_compact(bool flag, int* s_wave, int* runnin
 __global__ void __launch_bounds__(1024)
 best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
                  const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
-                 const int32_t* __restrict__ pos, double thr, int L, int cap_blocks, int32_t* __restrict__ sel,
+                 const int32_t* __restrict__ pos, double thr, int L, int32_t* __restrict__ sel,
                  uint8_t* __restrict__ li, int32_t* __restrict__ list,
                  const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table, int adaptive,
                  int n_hyp_init)
@@ -678,18 +679,17 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
         sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
         sel[SEL_LI_DEFER] = 0;                       // (an update stage that is re-run starts without a deferred covariance)
         sel[SEL_K_HI] = 0; sel[SEL_NBLK_HI] = 0;     // written by the second P H^T (GateList); no such launch without matched features
-        if (nblk > cap_blocks) sel[SEL_CAP_FLAG] = 1;   // launch sequence too short: re-run
     }
 }
 
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
-                      const int32_t* pos, double threshold, int L, int cap_blocks, int32_t* sel, uint8_t* li,
+                      const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
                       int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init)
 {
     int bs = score_block_size(m);
     if (bs < 256) bs = 256;          // the consensus scan wants a few waves even for tiny maps
-    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, cap_blocks, sel, li, list,
+    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, sel, li, list,
                                                   sup, H, nhyp_table, adaptive, n_hyp_init);
 }
 
@@ -700,7 +700,7 @@ void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const doub
 __global__ void __launch_bounds__(1024)
 rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restrict__ li,
                    const uint8_t* __restrict__ has_h, const double* __restrict__ S,
-                   const double* __restrict__ z, const double* __restrict__ h, double chi2, int cap_blocks,
+                   const double* __restrict__ z, const double* __restrict__ h, double chi2,
                    uint8_t* __restrict__ hi, int32_t* __restrict__ list, int32_t* __restrict__ sel)
 {
     __shared__ int s_wave[16];
@@ -727,18 +727,17 @@ rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restr
         const int nblk = (2 * s_running + 63) / 64;
         sel[SEL_K_HI] = s_running;
         sel[SEL_NBLK_HI] = nblk;
-        if (nblk > cap_blocks) sel[SEL_CAP_FLAG] = 1;
     }
 }
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
-                        const double* S, const double* z, const double* h, double chi2, int cap_blocks,
+                        const double* S, const double* z, const double* h, double chi2,
                         uint8_t* hi, int32_t* list, int32_t* sel)
 {
     int bs = ((L + 63) / 64) * 64;
     if (bs < 64) bs = 64;
     if (bs > 1024) bs = 1024;
-    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, cap_blocks, hi, list, sel);
+    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, hi, list, sel);
 }
 
 // ---------------------------------------------------------------------------
@@ -864,7 +863,7 @@ constexpr int CD_LD = 65;
 constexpr int CD_TW = 4;            // T waves
 constexpr int CD_MW = 2;            // M waves
 constexpr int CD_THREADS = 64 * (2 + CD_TW + CD_MW);
-constexpr int CD_SPIN_LIMIT = 1 << 20;
+constexpr int CD_SPIN_LIMIT = 1 << 13;       // ~1 ms of LDS polls; the waves of the pipeline are never more than a pivot step (~0.6 us) apart
 constexpr int CD_OPLD = 72;         // leading dimension of the operands staged for the in-kernel panel row
 
 struct CdShared {
@@ -1758,7 +1757,16 @@ struct SweepFlags {
                                         // producer, no atomics: the tile workers poll the strips of their own row blocks
 };
 static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag block size");
-constexpr int SW_SPIN_LIMIT = 1 << 15;       // ~30 ms (a poll is ~1 us); the longest legitimate wait is one diagonal block (~15 us)
+// Every wait on another workgroup is bounded in TIME (100 MHz wall clock): the longest legitimate wait is one diagonal block
+// of the chain (~15 us) -- the budget is ~70 times that, so that a launch whose workgroups are not all resident (another user
+// of the device) costs about one frame before the host falls back to the launch-per-step route, not the ~30 ms (140 frames)
+// of the spin-count bound that stood here until round 3.
+constexpr unsigned long long SW_WAIT_TICKS = 100ull * 1000;          // 1 ms
+struct SwDeadline {
+    unsigned long long t0; int n;
+    __device__ __forceinline__ SwDeadline() : t0(wall_clock64()), n(0) {}
+    __device__ __forceinline__ bool expired() { return ((++n & 7) == 0) && (wall_clock64() - t0 > SW_WAIT_TICKS); }
+};
 
 // data that crosses workgroups inside the launch (see "Memory protocol" above)
 __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1776,7 +1784,7 @@ __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* 
 {
     if (threadIdx.x == 0) {
         // two polls in flight, half a memory latency apart: the flag is seen ~half a latency earlier than with one
-        int spins = 0;
+        SwDeadline dl;
         int a = ld_flag(flag);
         while (true) {
             __builtin_amdgcn_s_sleep(4);
@@ -1785,7 +1793,7 @@ __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* 
             __builtin_amdgcn_s_sleep(4);
             a = ld_flag(flag);
             if (b >= need) break;
-            if (++spins > SW_SPIN_LIMIT) { atomicMin(status, -(30 + code)); *abort = 1; break; }
+            if (dl.expired()) { atomicMin(status, -(30 + code)); *abort = 1; break; }
         }
     }
     __syncthreads();
@@ -1797,11 +1805,11 @@ __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* 
 __device__ __forceinline__ bool sw_wait2(const int32_t* fa, int na, const int32_t* fb, int nb, int32_t* status, int* abort, int code)
 {
     if (threadIdx.x == 0) {
-        int spins = 0;
+        SwDeadline dl;
         while (true) {
             const int a = ld_flag(fa), b = ld_flag(fb);
             if (a >= na && b >= nb) break;
-            if (++spins > SW_SPIN_LIMIT) { atomicMin(status, -(30 + code)); *abort = 1; break; }
+            if (dl.expired()) { atomicMin(status, -(30 + code)); *abort = 1; break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -2343,9 +2351,9 @@ __device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, doub
     if (st == 3) return;
     if (st != 4) {
         if (nx.flag && st != 7) {
-            int spins = 0;
+            SwDeadline dl;
             while (ld_flag(nx.flag) < nx.need) {
-                if (++spins > SW_SPIN_LIMIT) { sh.timeout = 5; break; }
+                if (dl.expired()) { sh.timeout = 5; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -2916,11 +2924,11 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
     for (int k = 0; k < nblk; ++k) {
         if (timing && t == 0 && k < SWD_K) dbg[(5 * SWD_K + k) * SWD_SLOT + 1] = wall_clock64();
         if (t < 64) {
-            int spins = 0;
+            SwDeadline dl;
             while (true) {
                 const int v = my_flag >= 0 ? ld_flag(&fl->y_flag[my_flag]) : k + 1;
                 if (__all(v >= k + 1)) break;
-                if (++spins > SW_SPIN_LIMIT) { if (t == 0) { atomicMin(status, -37); *abort = 1; } break; }
+                if (dl.expired()) { if (t == 0) { atomicMin(status, -37); *abort = 1; } break; }
                 __builtin_amdgcn_s_sleep(4);
             }
         }
@@ -2949,9 +2957,9 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
             __syncthreads();
             if (fix && t4 < 64) {
                 // Jnorm comes from the strip of state rows 0..15 of this launch (xacc_finish), long ago
-                int spins = 0;
+                SwDeadline dl;
                 while (ld_flag(wk.xu_flag) < wk.token) {
-                    if (++spins > (1 << 16)) { atomicMin(status, -38); break; }
+                    if (dl.expired()) { atomicMin(status, -38); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 double T[16];
@@ -3106,6 +3114,8 @@ int init_kernel_attributes()
 // The persistent sweep needs every workgroup resident at once: one per CU (its dynamic LDS does not leave room for
 // a second), at most 16 column blocks (the accumulators of a strip are a compile-time array).
 // diagnostic time stamps of the persistent sweep (the last launch wins); off unless a buffer is installed
+// (diagnostic variant of the library only, -DRSLAM_DEBUG: the product build has neither the buffer nor the entry point)
+#if defined(RSLAM_DEBUG)
 static unsigned long long* g_sweep_dbg = nullptr;
 int debug_sweep_stamps(unsigned long long* out /* SWD_TOTAL, nullable = only (un)install */, int enable)
 {
@@ -3118,14 +3128,19 @@ int debug_sweep_stamps(unsigned long long* out /* SWD_TOTAL, nullable = only (un
     if (!enable && g_sweep_dbg) { (void)hipFree(g_sweep_dbg); g_sweep_dbg = nullptr; }
     return 0;
 }
+static unsigned long long* sweep_dbg_buffer() { return g_sweep_dbg; }
+#else
+static unsigned long long* sweep_dbg_buffer() { return nullptr; }
+#endif
 
-// RSLAM_SWEEP_EXP: bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
+// RSLAM_SWEEP_EXP (diagnostic variant of the library only; the product build always runs with mask 0): bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
 // shared route too, bit 3 no register-only route for systems of <= 4 rows, bit 4 fault injection (the chain
 // workgroup does not run), bit 5 fault injection (the strips never announce their Y blocks: tile workers and the x update
 // run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep), bit 8 the time
 // stamps of scripts/sweep_stamps.py come from the LI pass instead of the HI pass, bit 9 a low-innovation update of rank <= 4
 // streams P at once instead of deferring its covariance to the high-innovation pass;
 // set_sweep_exp_mask overrides the environment (tests)
+#if defined(RSLAM_DEBUG)
 static int g_sweep_exp_override = -1;
 void set_sweep_exp_mask(int mask) { g_sweep_exp_override = mask; }
 int sweep_exp_mask()
@@ -3133,6 +3148,11 @@ int sweep_exp_mask()
     static const int env = getenv("RSLAM_SWEEP_EXP") ? atoi(getenv("RSLAM_SWEEP_EXP")) : 0;
     return g_sweep_exp_override >= 0 ? g_sweep_exp_override : env;
 }
+static bool debug_env(const char* name) { return getenv(name) != nullptr; }      // measurement switches
+#else
+int sweep_exp_mask() { return 0; }
+static bool debug_env(const char*) { return false; }
+#endif
 
 static int device_cus()
 {
@@ -3146,7 +3166,7 @@ static int device_cus()
 
 bool sweep_persistent_eligible(const SystemDims& d)
 {
-    static const bool off = getenv("RSLAM_SWEEP_STEPS") != nullptr;       // measurement: the one-launch-per-step sequence
+    static const bool off = debug_env("RSLAM_SWEEP_STEPS");       // measurement: the one-launch-per-step sequence
     if (off || d.RP <= 0) return false;
     return d.RP / 64 <= 16 && 1 + d.ldA / 16 <= device_cus();
 }
@@ -3156,7 +3176,7 @@ bool sweep_persistent_eligible(const SystemDims& d)
 // count turns out to be (fewest workers: every S row block in use).
 bool sweep_fused_eligible(const SystemDims& d)
 {
-    static const bool off = getenv("RSLAM_SWEEP_UNFUSED_K10") != nullptr;  // measurement: rank update as a launch of its own
+    static const bool off = debug_env("RSLAM_SWEEP_UNFUSED_K10");  // measurement: rank update as a launch of its own
     if (off || (sweep_exp_mask() & 128) || !sweep_persistent_eligible(d)) return false;
     const int rp_blocks = d.RP / 64, nT = d.NP / 64;
     const int workers = device_cus() - 1 - d.ldA / 16 + 4 * (rp_blocks < 2 ? rp_blocks : 2) + 3;
@@ -3188,7 +3208,7 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
         const int set = (slot_k == SEL_K_LI) ? 0 : 1;              // the LI and the HI sweep of a frame alternate between the two flag sets
         int32_t* fl_cur = flags + set * SWEEP_FLAG_INTS;
         int32_t* fl_other = flags + (1 - set) * SWEEP_FLAG_INTS;
-#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, stamp_this ? g_sweep_dbg : nullptr, exp_mask, wa)
+#define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, stamp_this ? sweep_dbg_buffer() : nullptr, exp_mask, wa)
         if (rp_blocks <= 4) SWP_LAUNCH(4);
         else if (rp_blocks <= 8) SWP_LAUNCH(8);
         else if (rp_blocks <= 12) SWP_LAUNCH(12);
@@ -3232,7 +3252,6 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
             step += 2;
         }
         return Ystore;
-        return A;
     }
     if (steps <= 0) return Ystore;
     chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
@@ -3489,9 +3508,9 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     // block row/column, i.e. the pairs with bj == 0; same arithmetic as a separate pass over P would do
     if (Tq && bj == 0 && sel[slot_k] != 0) {
         if (xu.groups > 0) {                        // Jnorm comes from group 0 of this launch
-            int spins = 0;
+            SwDeadline dl;
             while (__hip_atomic_load(xu.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < xu.token) {
-                if (++spins > (1 << 16)) { atomicMin(xu.flag + (SEL_STATUS - SEL_XU_FLAG), -39); break; }   // (xu.flag = sel + SEL_XU_FLAG; ~50 ms)
+                if (dl.expired()) { atomicMin(xu.flag + (SEL_STATUS - SEL_XU_FLAG), -39); break; }   // (xu.flag = sel + SEL_XU_FLAG)
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -3573,8 +3592,9 @@ void make_rank_update_order(int nT, std::vector<int32_t>& order)
 }
 
 // diagnostic time stamps of the rank update (the last launch wins); off unless a buffer is installed
-static unsigned long long* g_k10_dbg = nullptr;
 constexpr int K10_DBG_WGS = 8192;
+#if defined(RSLAM_DEBUG)
+static unsigned long long* g_k10_dbg = nullptr;
 int debug_k10_stamps(unsigned long long* out /* K10_DBG_WGS * 8, nullable */, int enable)
 {
     const size_t bytes = sizeof(unsigned long long) * K10_DBG_WGS * 8;
@@ -3586,6 +3606,10 @@ int debug_k10_stamps(unsigned long long* out /* K10_DBG_WGS * 8, nullable */, in
     if (!enable && g_k10_dbg) { (void)hipFree(g_k10_dbg); g_k10_dbg = nullptr; }
     return 0;
 }
+static unsigned long long* k10_dbg_buffer() { return g_k10_dbg; }
+#else
+static unsigned long long* k10_dbg_buffer() { return nullptr; }
+#endif
 
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
@@ -3608,25 +3632,27 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
     // then the riders go last, group 0 still starts at once, and no tile waits for a rider to vacate its slot (the late
     // tiles ended the launch ~2 us late at C3).
     // (slots: what the device can hold of this kernel at once, from its real occupancy -- registers and dynamic LDS)
-    static int slots = -1;
+    // (one value per instantiation: the MAT one needs more registers and may hold fewer workgroups per compute unit)
+    static int slots_of[2] = {-1, -1};
+    int& slots = slots_of[mat ? 1 : 0];
     if (slots < 0) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rank_update_kernel<false>), 256,
-                                                         sizeof(double) * TG_LDS_DOUBLES) != hipSuccess) per_cu = 0;
+        const void* fn = mat ? reinterpret_cast<const void*>(rank_update_kernel<true>) : reinterpret_cast<const void*>(rank_update_kernel<false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, sizeof(double) * TG_LDS_DOUBLES) != hipSuccess) per_cu = 0;
         slots = per_cu * device_cus();
     }
-    static const bool riders_first = getenv("RSLAM_K10_RIDERS_FIRST") != nullptr;      // measurement
+    static const bool riders_first = debug_env("RSLAM_K10_RIDERS_FIRST");      // measurement
     // behind the tiles only when tiles AND riders all find a slot at once (then rider 0 is resident whatever the dispatch order);
     // x.riders_first: the host saw a timed-out Jnorm wait (somebody else holds compute units) and re-runs the safe order
     const int rider0 = (x.groups > 0 && tiles + x.groups <= slots && !riders_first && !x.riders_first) ? tiles : 0;
     if (mat)
         rank_update_kernel<true><<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
                                                                                                    fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, m, rider0,
-                                                                                                   (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);
+                                                                                                   (x.groups + tiles <= K10_DBG_WGS) ? k10_dbg_buffer() : nullptr);
     else
         rank_update_kernel<false><<<dim3(x.groups + tiles), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(nT, Pin, ldp, Y, ldy, sel, slot_nblk,
                                                                                                     fixed_k, Pout, ldo, tile_order, Tq, slot_k, x, m, rider0,
-                                                                                                    (x.groups + tiles <= K10_DBG_WGS) ? g_k10_dbg : nullptr);
+                                                                                                    (x.groups + tiles <= K10_DBG_WGS) ? k10_dbg_buffer() : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -3789,7 +3815,7 @@ int init_kernel_attributes2()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_update_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (getenv("RSLAM_DEBUG_OCCUPANCY")) {
+    if (debug_env("RSLAM_DEBUG_OCCUPANCY")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(rank_update_kernel<false>), 256, (size_t)bytes);
         fprintf(stderr, "[rslam] rank_update_kernel: %d workgroups per CU at %d B of dynamic LDS\n", nb, bytes);

@@ -99,7 +99,6 @@ struct rslam_ctx {
     const void* g1_sup = nullptr;
     const void* g2_sup = nullptr;
     const int32_t* last_sup = nullptr;
-    int reruns = 0;
     int graph_captures = 0;
     int last_raw_status = 0;
     // The persistent sweep needs its whole grid resident at once.  When a bounded wait runs out (somebody else is holding
@@ -109,10 +108,10 @@ struct rslam_ctx {
     int consecutive_fallbacks = 0;
     bool k10_riders_first = false;     // a Jnorm wait of the stand-alone rank update timed out once: riders in front from now on
     int k10_reruns = 0;
-    int k10_inject = 0;                // fault injection (tests)
+    int k10_inject = 0;                // fault injection (diagnostic variant of the library only)
+    void* checked_comm = nullptr;      // rslam_shard_frame: the communicator whose size / rank have been checked
     int rep_status = 0, rep_front = 0, rep_sticky = 0;   // status words of the frame in flight once read_status has taken them off the device
-    bool sweep_can_overflow = false;   // the update stage in flight was enqueued with a shortened sweep ...
-    bool frame_checked = true;         // ... and read_status has (not) looked at it yet
+    bool frame_checked = true;         // read_status has (not) looked at the update stage in flight yet
 };
 
 // bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
@@ -125,12 +124,9 @@ static bool sweep_is_persistent(const rslam_ctx* c)
 
 static void mark_update_enqueued(rslam_ctx* c, const int32_t* d_sup)
 {
-    const int rp_blocks = c->RP / 64;
+    // (the persistent sweep is one launch sized for the largest inlier count, the launch-per-step sweep is sized by the
+    //  host from this frame's own counts: no launch sequence can turn out too short)
     c->last_sup = d_sup;
-    // the persistent sweep is one launch sized for the largest inlier count, the launch-per-step sweep is sized by the
-    // host from this frame's own counts: nothing to overflow
-    (void)rp_blocks;
-    c->sweep_can_overflow = false;
     c->frame_checked = false;
     c->rep_status = c->rep_front = c->rep_sticky = 0;
     c->have_post = true;
@@ -488,7 +484,7 @@ static const int32_t* tile_order(rslam_ctx* c, int NP)
     return c->d_tile_order.p;
 }
 
-static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int cap, const double* Wsrc,
+static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int host_blocks, const double* Wsrc,
                               const double* H13,
                               const double* z_h, const double* x_in, double* x_out, const double* Pin, double* Pout,
                               int ev_f0, int ev_f1, int ev_r0, int ev_r1)
@@ -520,7 +516,7 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         wk.T = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
         wk.defer_flag = sel + SEL_LI_DEFER; wk.Y1 = c->d_Y1.p; wk.ldy1 = c->NP; wk.Ppred = c->d_Ppred.p; wk.T_li = c->d_T.p;
     }
-    Ysys = launch_factor_sweep(s, d, sel, slot_k, slot_nblk, cap, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
+    Ysys = launch_factor_sweep(s, d, sel, slot_k, slot_nblk, host_blocks, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
                                persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr, fused ? &wk : nullptr);
     if (ev_f1 >= 0) mark(c, ev_f1);
     if (c->RP <= 0) HIPCHK(hipMemcpyAsync(x_out, x_in, sizeof(double) * c->NP, hipMemcpyDeviceToDevice, s));
@@ -561,10 +557,10 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
         c->pht_done = true;
     }
     const bool persistent = sweep_is_persistent(c);
-    int cap_li = 1 << 20, cap_hi = 1 << 20;
+    int blocks_li = 1 << 20, blocks_hi = 1 << 20;          // launch-per-step route: read from the device below
     // K5 consensus (Tracking.cpp:507-537)
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
-                     c->cfg.sigma_z, c->L, cap_li, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
+                     c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
                      c->cfg.adaptive, c->cfg.n_hyp_init);
     mark(c, EV_SELECT);
     // Systems too large for the persistent sweep (more 16-row strips than compute units, e.g. 1000 landmarks) run one launch
@@ -576,14 +572,18 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
         int32_t cnt[SEL_NBLK_LI - SEL_K_LI + 1] = {0};            // sel[SEL_K_LI .. SEL_NBLK_LI]
         HIPCHK(hipMemcpyAsync(cnt, sel + SEL_K_LI, sizeof(cnt), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        cap_li = cnt[SEL_NBLK_LI - SEL_K_LI];
+        blocks_li = cnt[SEL_NBLK_LI - SEL_K_LI];
         // a low-innovation update of rank <= 4 (compat mode: Q1 leaves one or two inliers) does not stream P: kernels.h MatArgs
+#if defined(RSLAM_DEBUG)
         static const bool no_defer = getenv("RSLAM_NO_LI_DEFER") != nullptr;       // measurement
+#else
+        const bool no_defer = false;
+#endif
         c->li_defer_host = !no_defer && cnt[0] >= 1 && 2 * cnt[0] <= 4 && c->RP > 0;
     }
     // low-innovation update (ExtendKF.cpp:559-596)
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
-    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, cap_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
+    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, blocks_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
                                 c->d_Ppred.p, c->d_P.p, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0, EV_LI_RANK1);
     if (rc) return rc;
     mark(c, EV_LI_END);
@@ -595,7 +595,11 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     // workgroups of the second P H^T find their feature and the count from the flags (kernels.h GateArgs / GateList)
     // (large maps keep the gate as a launch: there the second P H^T has tens of thousands of workgroups that would each scan
     //  the flags -- measured at C5, 1000 landmarks: 25 us per frame more than the 6 us launch)
+#if defined(RSLAM_DEBUG)
     static const bool gate_env = getenv("RSLAM_GATE_APART") != nullptr;        // measurement: rescue_gate_kernel as a launch
+#else
+    const bool gate_env = false;
+#endif
     const bool gate_apart = gate_env || c->L > 512;
     const GateArgs ga{c->d_ic.p, c->d_li.p, c->d_z.p, c->cfg.chi2_gate, c->d_hi.p};
     launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
@@ -603,10 +607,10 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
                    c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr, &da, gate_apart ? nullptr : &ga);
     if (gate_apart)
         launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
-                           1 << 20, c->d_hi.p, c->d_hilist.p, sel);
+                           c->d_hi.p, c->d_hilist.p, sel);
     mark(c, EV_RESCUE);
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
-    const GateList gl{c->d_hi.p, c->L, c->d_hilist.p, sel, 1 << 20};
+    const GateList gl{c->d_hi.p, c->L, c->d_hilist.p, sel};
     if (c->RP > 0)
         launch_pht(s, c->d_P.p, c->NP, c->d_hilist.p, c->m, sel + SEL_K_HI, c->d_H13b.p, c->d_off.p, c->d_type.p,
                    c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &da,
@@ -615,9 +619,9 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
         int32_t nb = 0;
         HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_HI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        cap_hi = nb;
+        blocks_hi = nb;
     }
-    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, cap_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
+    rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, blocks_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
                             c->d_P.p, c->d_P.p, EV_HI_FACTOR0, EV_HI_FACTOR1, EV_HI_RANK0, EV_HI_RANK1);
     if (rc) return rc;
     mark(c, EV_HI_END);
@@ -669,7 +673,6 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         invalidate_graph(c);
         const int timing = c->timing; c->timing = 0;
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_CAP_FLAG, 0, sizeof(int32_t), c->stream));
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
         rc = enqueue_update(c, c->last_sup);
         c->timing = timing;
@@ -697,7 +700,6 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         invalidate_graph(c);
         const int timing = c->timing; c->timing = 0;
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_CAP_FLAG, 0, sizeof(int32_t), c->stream));
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
         HIPCHK(hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream));
         rc = enqueue_update(c, c->last_sup);
@@ -1201,7 +1203,7 @@ extern "C" int rslam_get_counters(rslam_ctx* c, int32_t* graph_captures, int32_t
 {
     if (!c) return RSLAM_ERR_ARG;
     if (graph_captures) *graph_captures = c->graph_captures;
-    if (sweep_reruns) *sweep_reruns = c->reruns + c->sweep_fallbacks + c->k10_reruns;
+    if (sweep_reruns) *sweep_reruns = c->sweep_fallbacks + c->k10_reruns;
     return RSLAM_OK;
 }
 
@@ -1302,21 +1304,32 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
 // ------------------------------------------------------------------------
 namespace {
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, void* /* ncclComm_t */, hipStream_t);
+typedef int (*nccl_comm_query_fn)(void* /* const ncclComm_t */, int*);
 constexpr int NCCL_INT32 = 2;               // ncclInt32 / ncclInt, rccl.h
 
-nccl_allgather_fn bind_allgather()
+struct RcclBinding { nccl_allgather_fn allgather; nccl_comm_query_fn count, user_rank; };
+
+const RcclBinding& bind_rccl()
 {
-    static nccl_allgather_fn fn = []() -> nccl_allgather_fn {
+    static const RcclBinding b = []() -> RcclBinding {
         // the RCCL the process already uses (the caller created its communicator with it), else the system one
-        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
-        if (!sym) {
-            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (h) sym = dlsym(h, "ncclAllGather");
-        }
-        return reinterpret_cast<nccl_allgather_fn>(sym);
+        void* h = nullptr;
+        auto find = [&](const char* name) -> void* {
+            void* sym = dlsym(RTLD_DEFAULT, name);
+            if (!sym) {
+                if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) sym = dlsym(h, name);
+            }
+            return sym;
+        };
+        RcclBinding r;
+        r.allgather = reinterpret_cast<nccl_allgather_fn>(find("ncclAllGather"));
+        r.count = reinterpret_cast<nccl_comm_query_fn>(find("ncclCommCount"));
+        r.user_rank = reinterpret_cast<nccl_comm_query_fn>(find("ncclCommUserRank"));
+        return r;
     }();
-    return fn;
+    return b;
 }
 }  // namespace
 
@@ -1341,8 +1354,17 @@ extern "C" int rslam_shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, in
     if (rc) return rc;
     int32_t* full = c->d_sup_local.p;
     if (nccl_comm) {
-        nccl_allgather_fn allgather = bind_allgather();
+        const RcclBinding& rccl = bind_rccl();
+        nccl_allgather_fn allgather = rccl.allgather;
         if (!allgather) return RSLAM_ERR_COMM;
+        if (c->checked_comm != nccl_comm) {
+            // a communicator of another size, or this process under another index in it, would leave the all-gather hanging
+            // (or scatter the slices wrongly): checked once per communicator, before its first collective
+            int cnt = -1, me = -1;
+            if (!rccl.count || !rccl.user_rank || rccl.count(nccl_comm, &cnt) != 0 || rccl.user_rank(nccl_comm, &me) != 0) return RSLAM_ERR_COMM;
+            if (cnt != world || me != rank) return RSLAM_ERR_COMM;
+            c->checked_comm = nccl_comm;
+        }
         if (allgather(c->d_sup_local.p, c->d_sup_all.p, (size_t)chunk, NCCL_INT32, nccl_comm, c->stream) != 0) return RSLAM_ERR_COMM;
         full = c->d_sup_all.p;
     }
@@ -1509,7 +1531,23 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
     return RSLAM_OK;
 }
 
-// diagnostics (not part of include/rslam.h) behind the value-level tests of the scoring arithmetic (tests/test_gpu_scoring.py):
+// which bounded wait of the last frame ran out (0: none): the raw device-side code that rslam_sync folds into RSLAM_ERR_HIP
+extern "C" int rslam_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
+// how the update stage of the loaded frame shape runs: 0 launch-per-step sweep + stand-alone rank update, 1 persistent sweep +
+// stand-alone rank update, 2 persistent sweep with the x / covariance update inside its launch
+extern "C" int rslam_update_mode(rslam_ctx* c)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
+    if (!sweep_is_persistent(c)) return 0;
+    return sweep_fused_eligible(d) ? 2 : 1;
+}
+
+#if defined(RSLAM_DEBUG)
+// ------------------------------------------------------------------------
+// Diagnostic variant of the library only (librslam_hip_dbg.so, -DRSLAM_DEBUG): value-level probes, time stamps and fault
+// injection for the tests and scripts of this repository.  None of this is compiled into the product library.
+// ------------------------------------------------------------------------
 // the squared residuals score_kernel compares with sigma_z^2, for every hypothesised position of the resident frame
 // (out: host, m * m, row = matched rank of the hypothesised feature); needs a frame whose scoring stage has been enqueued
 extern "C" int rslam_debug_score_residuals(rslam_ctx* c, double* out, int32_t* m_out)
@@ -1545,26 +1583,14 @@ extern "C" int rslam_debug_distort(rslam_ctx* c, int32_t n, const double* uv, do
     return RSLAM_OK;
 }
 
-// diagnostic (not part of include/rslam.h): time stamps of the persistent factor sweep, see scripts/sweep_stamps.py
-namespace rslam { int debug_sweep_stamps(unsigned long long* out, int enable); }
-extern "C" int rslam_debug_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
-// how the update stage of the loaded frame shape runs: 0 launch-per-step sweep + stand-alone rank update, 1 persistent sweep +
-// stand-alone rank update, 2 persistent sweep with the x / covariance update inside its launch
-extern "C" int rslam_debug_update_mode(rslam_ctx* c)
-{
-    if (!c) return RSLAM_ERR_ARG;
-    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
-    if (!sweep_is_persistent(c)) return 0;
-    return sweep_fused_eligible(d) ? 2 : 1;
-}
-// diagnostics / fault injection (not part of include/rslam.h): RSLAM_SWEEP_EXP switches from the host, -1 = environment.
-// PROCESS-WIDE, like the two stamp buffers below (one per process, the last stamped launch wins): these entry points exist for
-// the tests and scripts of this repository, which drive one context at a time; they are not synchronised against contexts of
-// other threads and a product build would compile them out.  Everything the product path reads is per context.
+// RSLAM_SWEEP_EXP switches from the host, -1 = environment.  PROCESS-WIDE, like the two stamp buffers below (one per
+// process, the last stamped launch wins): the tests and scripts drive one context at a time.
 extern "C" int rslam_debug_set_sweep_exp(int mask) { rslam::set_sweep_exp_mask(mask); return RSLAM_OK; }
-// fault injection (tests), per context: riders of the stand-alone rank update that sit behind the tiles never publish Jnorm
+// fault injection, per context: riders of the stand-alone rank update that sit behind the tiles never publish Jnorm
 extern "C" int rslam_debug_set_k10_inject(rslam_ctx* c, int on) { if (!c) return RSLAM_ERR_ARG; c->k10_inject = on ? 1 : 0; invalidate_graph(c); return RSLAM_OK; }
 
+// time stamps of the persistent factor sweep, see scripts/sweep_stamps.py
+namespace rslam { int debug_sweep_stamps(unsigned long long* out, int enable); }
 extern "C" int rslam_debug_sweep_stamps(rslam_ctx* c, unsigned long long* out, int enable)
 {
     if (!c) return RSLAM_ERR_ARG;
@@ -1593,6 +1619,7 @@ extern "C" int rslam_debug_cd_stamps(rslam_ctx* c, unsigned long long* out, int 
     return rslam::debug_read_cd_stamps(out, reset) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
 }
 #endif
+#endif   // RSLAM_DEBUG
 
 extern "C" int rslam_k_hbm_copy_peak(rslam_ctx* c, int64_t bytes, double* gbps)
 {

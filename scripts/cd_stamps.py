@@ -2,13 +2,12 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ransac_slam_amd import default_config, api
-api.LIB_PATH = sys.argv[1]
-del api.SYMBOLS["rslam_k_mfma4_raw"]
+api.LIB_PATH_DEBUG = sys.argv[1]          # a -DRSLAM_DEBUG -DCD_STAMPS build (ransac_slam_amd/build.py: extra_flags)
 from ransac_slam_amd.synth import make_frame
 fr = make_frame(L=300, H=1000, seed=2)
-ctx = api.RslamHip(default_config(compat=1, adaptive=0))
+ctx = api.RslamHip(default_config(compat=1, adaptive=0), debug=True)
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
-L = api.lib()
+L = api.lib(debug=True)
 L.rslam_debug_cd_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 out = (C.c_ulonglong * 16)()
 for _ in range(3):

@@ -6,7 +6,6 @@ from ransac_slam_amd import api, default_config
 from ransac_slam_amd.synth import make_frame
 from oracle import pyoracle as po
 L, H, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-api.lib().rslam_debug_set_sweep_exp.argtypes = [C.c_int]
 fr = make_frame(L=L, H=H, seed=seed)
 for compat in (1, 0):
     cfg = default_config(compat=compat, adaptive=0)
@@ -15,8 +14,8 @@ for compat in (1, 0):
     ic = (fr.ic & v0).astype(np.uint8)
     r0 = o.ransac_update(fr.z, ic, fr.draws)
     for mask in (0, 64, 128):
-        api.lib().rslam_debug_set_sweep_exp(mask)
-        g = api.RslamHip(cfg)
+        api.lib(debug=True).rslam_debug_set_sweep_exp(mask)
+        g = api.RslamHip(cfg, debug=True)
         g.predict(fr.types, fr.x_pred, fr.P_pred)
         try:
             r1 = g.ransac_update(fr.z, ic, fr.draws)
@@ -28,4 +27,4 @@ for compat in (1, 0):
         print("compat", compat, "mask", mask, "n_li", int(r1["li"].sum()), "n_hi", int(r1["hi"].sum()), "bad tiles", len(bad), bad[:12],
               "dx", np.abs(r1["x_new"] - r0["x_new"]).max())
         g.close()
-api.lib().rslam_debug_set_sweep_exp(-1)
+api.lib(debug=True).rslam_debug_set_sweep_exp(-1)

@@ -27,7 +27,7 @@ def run(c, tag, n=40, chunk=1, graph=True):
             c.sync()
             st = 0
         except api.RslamError as e:
-            st = api.lib().rslam_debug_last_raw_status(c._h)
+            st = c.last_raw_status()
         out.append(((time.perf_counter() - t0) / chunk * 1e3, st))
         if not graph:
             dev.append(c.timings()["total_us"] * 1e-3)

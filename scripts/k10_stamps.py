@@ -16,13 +16,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--compat", type=int, default=1)
 a = ap.parse_args()
 fr = make_frame(L=300, H=1000, seed=2)
-ctx = api.RslamHip(default_config(compat=a.compat, adaptive=0))
+ctx = api.RslamHip(default_config(compat=a.compat, adaptive=0), debug=True)     # stamps: diagnostic variant of the library
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
 ctx.step_predict(); ctx.sync()
 ic = fr.ic & ctx.fetch_prediction()[1]
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
-fn = api.lib().rslam_debug_k10_stamps
-fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+fn = api.lib(debug=True).rslam_debug_k10_stamps
 for _ in range(3):
     ctx.step_frame(False); ctx.sync()
 assert fn(ctx._h, None, 1) == 0

@@ -21,16 +21,14 @@ ap.add_argument("--seed", type=int, default=2)
 ap.add_argument("--li", action="store_true", help="stamps of the LI pass (RSLAM_SWEEP_EXP bit 8) instead of the HI pass")
 a = ap.parse_args()
 if a.li:
-    api.lib().rslam_debug_set_sweep_exp.argtypes = [C.c_int]
-    api.lib().rslam_debug_set_sweep_exp(256)
+    api.lib(debug=True).rslam_debug_set_sweep_exp(256)
 fr = make_frame(L=a.L, H=a.H, seed=a.seed)
-ctx = api.RslamHip(default_config(compat=a.compat, adaptive=0))
+ctx = api.RslamHip(default_config(compat=a.compat, adaptive=0), debug=True)     # stamps: diagnostic variant of the library
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
 ctx.step_predict(); ctx.sync()
 ic = fr.ic & ctx.fetch_prediction()[1]
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
-fn = api.lib().rslam_debug_sweep_stamps
-fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+fn = api.lib(debug=True).rslam_debug_sweep_stamps
 for _ in range(3):
     ctx.step_frame(False); ctx.sync()
 assert fn(ctx._h, None, 1) == 0

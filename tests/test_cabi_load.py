@@ -27,6 +27,25 @@ def test_exports_every_declared_symbol(hip_lib):
     assert declared == set(hip_lib.SYMBOLS), declared ^ set(hip_lib.SYMBOLS)
 
 
+def test_product_library_exports_no_diagnostics(hip_lib):
+    """Fault injection, time stamps and value probes (rslam_debug_*) exist in the diagnostic variant only
+    (librslam_hip_dbg.so, -DRSLAM_DEBUG); the product library exports exactly the header's entry points."""
+    import subprocess
+    from ransac_slam_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and "rslam_" in ln.split()[-1] and not ln.split()[-1].startswith("_Z")}
+    assert exported == set(hip_lib.SYMBOLS), exported ^ set(hip_lib.SYMBOLS)
+    assert not [n for n in exported if "debug" in n]
+    dbg = subprocess.run(["nm", "-D", "--defined-only", build.LIB_DEBUG], capture_output=True, text=True, check=True).stdout
+    for name in hip_lib.DEBUG_SYMBOLS:
+        assert name in dbg, name
+    # ... and no behaviour switch is read from the environment of a deployed node
+    blob = open(build.LIB, "rb").read()
+    for env in (b"RSLAM_SWEEP_EXP", b"RSLAM_SWEEP_STEPS", b"RSLAM_GATE_APART", b"RSLAM_NO_LI_DEFER", b"RSLAM_SWEEP_UNFUSED_K10",
+                b"RSLAM_K10_RIDERS_FIRST"):
+        assert env not in blob, env
+
+
 def test_struct_sizes_match_header_layout():
     from ransac_slam_amd.ctypes_defs import Camera, Config, Layout, StageTimes
     assert C.sizeof(Camera) == 7 * 8 + 2 * 4

@@ -222,17 +222,18 @@ def test_sharded_frame_hip_engine_two_ranks_one_device(hip):
 
 # --------------------------------------------------------------------------- unsynced pipeline
 def test_unsynced_frame_into_ekf_prediction(hip, oracle_lib):
-    """A low-inlier frame (synced) sizes the factor sweep small; the next, high-inlier frame runs through
-    step_frame and straight into rslam_ekf_prediction with no rslam_sync in between: the prior that comes out
-    must be the oracle's (a sweep that was enqueued too short has to be noticed and re-run before its
-    posterior is propagated)."""
+    """Frames with (almost) no inliers, then a frame where everything is an inlier runs through rslam_step_frame and
+    straight into rslam_ekf_prediction with NO rslam_sync in between: the prior that comes out must be the oracle's.
+    Nothing of the earlier frames may leak into the launch sequence of the later one (no re-run, no re-capture), and the
+    status of the unsynchronised frame is settled by rslam_ekf_prediction itself."""
     cfg = default_config(compat=0, adaptive=1)
     lo = make_frame(L=150, H=120, seed=311, frac_outlier=1.0)
     hi_fr = make_frame(L=150, H=120, seed=313, frac_outlier=0.0)
     g = hip.RslamHip(cfg)
-    for _ in range(3):                                  # caps shrink at syncs
+    for _ in range(3):
         g.load_frame(lo.types, lo.x_pred, lo.P_pred, lo.z, lo.ic, lo.draws)
         g.step_frame(True); g.sync()
+    c0 = g.counters()
     o = oracle_lib.Oracle(cfg, structure=1)
     _, v0, _ = o.predict(hi_fr.types, hi_fr.x_pred, hi_fr.P_pred)
     ic = (hi_fr.ic & v0).astype(np.uint8)
@@ -244,6 +245,10 @@ def test_unsynced_frame_into_ekf_prediction(hip, oracle_lib):
     g.ekf_prediction(1.0, 0.007, 0.007)
     xp1, Pp1 = g.fetch_prior()
     assert close_x(xp1, xp0) and close_P(Pp1, Pp0)
+    c1 = g.counters()
+    assert c1["sweep_reruns"] == 0
+    if int(ic.sum()) == int(lo.ic.sum()):               # same number of matched features = same shape: the same graph
+        assert c1["graph_captures"] == c0["graph_captures"]
     g.close()
 
 

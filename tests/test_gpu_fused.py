@@ -2,7 +2,7 @@
 the host's handling of frames nobody has looked at yet.  Replaces ExtendKF::update's tail (ExtendKF.cpp:606-634)
 on a different schedule, so every route is held against the oracle and against the stand-alone rank update.
 """
-import ctypes as C
+import time
 
 import numpy as np
 import pytest
@@ -19,10 +19,6 @@ def hip():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device (the product path has no CPU fallback)")
     from ransac_slam_amd import api
-    L = api.lib()
-    L.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
-    L.rslam_debug_last_raw_status.argtypes = [C.c_void_p]
-    L.rslam_debug_set_k10_inject.argtypes = [C.c_void_p, C.c_int]
     return api
 
 
@@ -48,7 +44,7 @@ def oracle_frame(oracle_lib, fr, cfg, z=None, draws=None):
 
 @pytest.mark.parametrize("compat,L,H,seed", [(1, 90, 120, 21), (0, 24, 60, 12), (0, 40, 80, 13), (0, 90, 120, 13), (1, 300, 200, 2),
                                              (0, 300, 200, 2)])
-def test_fused_update_equals_standalone_rank_update(hip, oracle_lib, compat, L, H, seed):
+def test_fused_update_equals_standalone_rank_update(hip_dbg, oracle_lib, compat, L, H, seed):
     """Same frame with the update inside the sweep launch (default) and with the rank update as a launch of its own
     (RSLAM_SWEEP_EXP bit 7): both against the oracle, and against each other to rounding.  The frames cover the
     register-only route (r <= 4), the in-LDS single-block route, and systems of several diagonal blocks."""
@@ -57,14 +53,14 @@ def test_fused_update_equals_standalone_rank_update(hip, oracle_lib, compat, L, 
     ic, r0 = oracle_frame(oracle_lib, fr, cfg)
     out = {}
     for mask in (0, 128):
-        hip.lib().rslam_debug_set_sweep_exp(mask)
+        hip_dbg.set_sweep_exp(mask)
         try:
-            g = hip.RslamHip(cfg)
+            g = hip_dbg.RslamHip(cfg)
             g.predict(fr.types, fr.x_pred, fr.P_pred)
             out[mask] = g.ransac_update(fr.z, ic, fr.draws)
             g.close()
         finally:
-            hip.lib().rslam_debug_set_sweep_exp(-1)
+            hip_dbg.set_sweep_exp(-1)
         r1 = out[mask]
         assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
         assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"]), mask
@@ -101,28 +97,55 @@ def test_alternating_frames_on_one_context(hip, oracle_lib):
     g.close()
 
 
-def test_tile_workers_timeout_falls_back(hip, oracle_lib):
+def test_tile_workers_timeout_falls_back(hip_dbg, oracle_lib):
     """Fault injection (RSLAM_SWEEP_EXP bit 5): the strips never announce their Y blocks.  Every tile worker and every
     x-update strip must leave through its bounded wait WITHOUT writing the posterior, the host must notice, re-run the
     update stage on the launch-per-step sweep + stand-alone rank update, and return the right answer."""
     fr = make_frame(L=90, H=120, seed=321)
     cfg = default_config(compat=0, adaptive=1)
     ic, r0 = oracle_frame(oracle_lib, fr, cfg)
-    hip.lib().rslam_debug_set_sweep_exp(32)
+    hip_dbg.set_sweep_exp(32)
     try:
-        g = hip.RslamHip(cfg)
+        g = hip_dbg.RslamHip(cfg)
         g.predict(fr.types, fr.x_pred, fr.P_pred)
         r1 = g.ransac_update(fr.z, ic, fr.draws)
     finally:
-        hip.lib().rslam_debug_set_sweep_exp(-1)
-    assert hip.lib().rslam_debug_last_raw_status(g._h) in (-37, -38)
+        hip_dbg.set_sweep_exp(-1)
+    assert g.last_raw_status() in (-37, -38)
     assert g.counters()["sweep_reruns"] >= 1
     assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
     assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
     g.close()
+    # What a timeout costs: the waits are bounded in TIME (1 ms of the device's wall clock, kernels.hip SW_WAIT_TICKS), so a
+    # frame whose workgroups are not all resident is back -- timed out, noticed by the host, re-run on the launch-per-step
+    # route -- within ~3 ms of a healthy frame (until round 3 the bound was a spin count worth ~30 ms: 140 frames).
+    def frame_ms(mask):
+        hip_dbg.set_sweep_exp(mask)
+        try:
+            gg = hip_dbg.RslamHip(cfg)
+            gg.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+            gg.step_frame(False); gg.sync()                # (first launch of the context: module load, buffers)
+            if mask:
+                assert gg.counters()["sweep_reruns"] >= 1
+            ts = []
+            for _ in range(3):
+                gg2 = hip_dbg.RslamHip(cfg)                # a fresh context: no fallback state carried over
+                gg2.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+                t0 = time.perf_counter()
+                gg2.step_frame(False); gg2.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+                if mask:
+                    assert gg2.counters()["sweep_reruns"] == 1 and gg2.last_raw_status() in (-37, -38)
+                gg2.close()
+            gg.close()
+            return min(ts)
+        finally:
+            hip_dbg.set_sweep_exp(-1)
+    t_ok, t_fault = frame_ms(0), frame_ms(32)
+    assert t_fault - t_ok <= 3.0, (t_ok, t_fault)
 
 
-def test_unchecked_timeout_is_settled_before_ekf_prediction(hip, oracle_lib):
+def test_unchecked_timeout_is_settled_before_ekf_prediction(hip_dbg, oracle_lib):
     """A persistent sweep that timed out in a frame nobody synchronised on (rslam_step_frame, no rslam_sync) must be
     noticed and re-run when rslam_ekf_prediction turns its posterior into the next prior -- while the frame's inputs are
     still in place -- and rslam_load_measurements for the next frame must then simply work."""
@@ -130,15 +153,15 @@ def test_unchecked_timeout_is_settled_before_ekf_prediction(hip, oracle_lib):
     cfg = default_config(compat=0, adaptive=1)
     ic, r0 = oracle_frame(oracle_lib, fr, cfg)
     xp0, Pp0 = oracle_lib.ekf_prediction(r0["x_new"], r0["P_new"], 1.0, 0.007, 0.007)
-    hip.lib().rslam_debug_set_sweep_exp(16)              # the chain workgroup never shows up
+    hip_dbg.set_sweep_exp(16)              # the chain workgroup never shows up
     try:
-        g = hip.RslamHip(cfg)
+        g = hip_dbg.RslamHip(cfg)
         g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
         g.step_frame(True)                               # enqueued, not looked at
         g.ekf_prediction(1.0, 0.007, 0.007)              # must settle the frame first (re-run inside)
     finally:
-        hip.lib().rslam_debug_set_sweep_exp(-1)
-    assert hip.lib().rslam_debug_last_raw_status(g._h) <= -30 and g.counters()["sweep_reruns"] >= 1
+        hip_dbg.set_sweep_exp(-1)
+    assert g.last_raw_status() <= -30 and g.counters()["sweep_reruns"] >= 1
     xp1, Pp1 = g.fetch_prior()
     assert close_x(xp1, xp0) and close_P(Pp1, Pp0)
     z2, _, d2 = remeasure(fr, 77, frac_outlier=0.2, H=120)
@@ -148,7 +171,7 @@ def test_unchecked_timeout_is_settled_before_ekf_prediction(hip, oracle_lib):
     g.close()
 
 
-def test_rank_update_rider_timeout_reruns_with_riders_first(hip, oracle_lib):
+def test_rank_update_rider_timeout_reruns_with_riders_first(hip_dbg, oracle_lib):
     """The stand-alone rank update (systems the sweep cannot host: here forced by RSLAM_SWEEP_EXP bit 7) places the x-update
     riders behind the tiles when everything is resident at once.  Fault injection: such riders never publish Jnorm -- the
     first block column runs into its bounded wait (-39), the host re-runs the update stage with the riders in front and
@@ -156,13 +179,13 @@ def test_rank_update_rider_timeout_reruns_with_riders_first(hip, oracle_lib):
     fr = make_frame(L=90, H=120, seed=323)
     cfg = default_config(compat=0, adaptive=1)
     ic, r0 = oracle_frame(oracle_lib, fr, cfg)
-    hip.lib().rslam_debug_set_sweep_exp(128)
+    hip_dbg.set_sweep_exp(128)
     try:
-        g = hip.RslamHip(cfg)
-        hip.lib().rslam_debug_set_k10_inject(g._h, 1)
+        g = hip_dbg.RslamHip(cfg)
+        g.debug_set_k10_inject(1)
         g.predict(fr.types, fr.x_pred, fr.P_pred)
         r1 = g.ransac_update(fr.z, ic, fr.draws)
-        assert hip.lib().rslam_debug_last_raw_status(g._h) == -39 and g.counters()["sweep_reruns"] >= 1
+        assert g.last_raw_status() == -39 and g.counters()["sweep_reruns"] >= 1
         assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
         assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
         n_before = g.counters()["sweep_reruns"]
@@ -171,7 +194,7 @@ def test_rank_update_rider_timeout_reruns_with_riders_first(hip, oracle_lib):
         assert g.counters()["sweep_reruns"] == n_before and close_P(r2["P_new"], r0["P_new"])
         g.close()
     finally:
-        hip.lib().rslam_debug_set_sweep_exp(-1)
+        hip_dbg.set_sweep_exp(-1)
 
 
 def test_status_of_an_unsynced_frame_is_not_lost(hip):
@@ -197,7 +220,7 @@ def test_status_of_an_unsynced_frame_is_not_lost(hip):
 
 
 @pytest.mark.parametrize("L,H,seed", [(90, 120, 21), (300, 200, 2), (40, 100, 7)])
-def test_deferred_li_covariance_equals_immediate(hip, oracle_lib, L, H, seed):
+def test_deferred_li_covariance_equals_immediate(hip_dbg, oracle_lib, L, H, seed):
     """A low-innovation update of rank <= 4 (compat = 1: the consensus set is the hypothesis' own feature) does not stream P:
     Y1 and its Jnorm are kept aside and the rescue prediction, the second P H^T and the HI pass's tile workers form
     P_li = J (sym(P_pred) - Y1 Y1^T) J^T themselves (SEL_LI_DEFER).  Same frame with the deferral (default), with the
@@ -209,14 +232,14 @@ def test_deferred_li_covariance_equals_immediate(hip, oracle_lib, L, H, seed):
     assert int(r0["li"].sum()) in (1, 2)
     out = {}
     for mask in (0, 512, 128):
-        hip.lib().rslam_debug_set_sweep_exp(mask)
+        hip_dbg.set_sweep_exp(mask)
         try:
-            g = hip.RslamHip(cfg)
+            g = hip_dbg.RslamHip(cfg)
             g.predict(fr.types, fr.x_pred, fr.P_pred)
             out[mask] = g.ransac_update(fr.z, ic, fr.draws)
             g.close()
         finally:
-            hip.lib().rslam_debug_set_sweep_exp(-1)
+            hip_dbg.set_sweep_exp(-1)
         r1 = out[mask]
         assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"]), mask
         assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"]), mask

@@ -249,51 +249,57 @@ def test_sharded_scoring_equals_full(hip):
     c.close()
 
 
-def test_sweep_launch_sizing_overflow_reruns(hip, oracle_lib):
-    """The factor sweep is enqueued for the previous frame's inlier count (+1 block); a frame
-    that needs more blocks must be detected on the device and re-run at full length."""
+def test_launch_sequence_independent_of_inlier_counts(hip, oracle_lib):
+    """The update stage is sized on the host without looking at any earlier frame: the persistent sweep is ONE launch sized
+    for the largest inlier count the frame can have (idle strips become tile workers), so frames whose inlier counts go
+    0 -> all -> few on one context must all be right with ZERO re-runs and the hipGraph captured once per shape.
+    (Rounds 1-2 sized the sweep from the previous frame and re-ran on overflow; that machinery is gone.)"""
     cfg = default_config(compat=0, adaptive=1)
     g = hip.RslamHip(cfg)
-    frames = [make_frame(L=150, H=120, seed=311, frac_outlier=1.0),    # almost no inliers -> caps shrink
+    frames = [make_frame(L=150, H=120, seed=311, frac_outlier=1.0),    # almost no inliers
               make_frame(L=150, H=120, seed=312, frac_outlier=1.0),
-              make_frame(L=150, H=120, seed=313, frac_outlier=0.0),    # everything an inlier -> overflow
+              make_frame(L=150, H=120, seed=313, frac_outlier=0.0),    # everything an inlier
               make_frame(L=150, H=120, seed=314, frac_outlier=0.1)]
+    counts, caps = [], []
     for fr in frames:
         o = oracle_lib.Oracle(cfg, structure=1)
         _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
         ic = (fr.ic & v0).astype(np.uint8)
         r0 = o.ransac_update(fr.z, ic, fr.draws)
-        g.predict(fr.types, fr.x_pred, fr.P_pred)
-        r1 = g.ransac_update(fr.z, ic, fr.draws)
+        g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+        g.step_frame(True); g.sync()
+        r1 = g.fetch_results()
         assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
         assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
-    assert frames and int(r0["li"].sum()) > 0
+        counts.append(int(r0["li"].sum()) + int(r0["hi"].sum()))
+        caps.append((int(ic.sum()), g.counters()))
+    assert min(counts) <= 15 and max(counts) >= 120                    # the sequence does swing from a dozen inliers to (almost) all 150
+    assert all(c["sweep_reruns"] == 0 for _, c in caps)
+    # a graph is captured per frame SHAPE (number of matched features), never per inlier count
+    for (m_prev, c_prev), (m_cur, c_cur) in zip(caps, caps[1:]):
+        assert c_cur["graph_captures"] - c_prev["graph_captures"] == (0 if m_cur == m_prev else 1), (m_prev, m_cur)
     g.close()
 
 
-def test_persistent_sweep_timeout_falls_back(hip, oracle_lib):
+def test_persistent_sweep_timeout_falls_back(hip_dbg, oracle_lib):
     """The persistent factor sweep needs all its workgroups resident at once.  Fault injection (the chain workgroup does
     not show up, as if another user of the GPU held its CU): every strip must leave through its bounded wait, the host
     must notice, re-run the update stage with the launch-per-step sweep and return the right answer; the context keeps
     working (on the fallback path for a while)."""
-    import ctypes as C
     fr = make_frame(L=90, H=120, seed=321)
     cfg = default_config(compat=0, adaptive=1)
     o = oracle_lib.Oracle(cfg, structure=1)
     _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
     ic = (fr.ic & v0).astype(np.uint8)
     r0 = o.ransac_update(fr.z, ic, fr.draws)
-    lib = hip.lib()
-    lib.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
-    lib.rslam_debug_last_raw_status.argtypes = [C.c_void_p]
-    lib.rslam_debug_set_sweep_exp(16)
+    hip_dbg.set_sweep_exp(16)
     try:
-        g = hip.RslamHip(cfg)
+        g = hip_dbg.RslamHip(cfg)
         g.predict(fr.types, fr.x_pred, fr.P_pred)
         r1 = g.ransac_update(fr.z, ic, fr.draws)            # times out inside, recovers inside
     finally:
-        lib.rslam_debug_set_sweep_exp(-1)
-    assert lib.rslam_debug_last_raw_status(g._h) <= -30      # a hand-over wait did run out ...
+        hip_dbg.set_sweep_exp(-1)
+    assert g.last_raw_status() <= -30                        # a hand-over wait did run out ...
     assert g.counters()["sweep_reruns"] >= 1                # ... and the update stage was re-run
     assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
     assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
@@ -308,27 +314,24 @@ def test_persistent_sweep_timeout_falls_back(hip, oracle_lib):
 #  every strip; the last one has several diagonal blocks: the shared route in any case)
 @pytest.mark.parametrize("compat,L,H,seed,n_li", [(1, 90, 120, 21, 1), (0, 6, 30, 43, 2), (0, 24, 60, 12, 10), (0, 40, 80, 13, 29),
                                                   (0, 90, 120, 13, None)])
-def test_single_block_sweep_equals_shared_route(hip, compat, L, H, seed, n_li):
+def test_single_block_sweep_equals_shared_route(hip_dbg, compat, L, H, seed, n_li):
     """A system of one diagonal block (r <= 64) is factored by every strip workgroup itself, with no hand-over between
     workgroups; the shared route (chain workgroup + flags, forced by RSLAM_SWEEP_EXP bit 2) runs the same arithmetic on the
     same numbers: the posterior must be bit-identical.  Systems of <= 4 rows (compat = 1: the LI update is always rank 2)
     take a register-only route with full-precision sqrt / division (bit 3 switches it off): equal to rounding."""
-    import ctypes as C
     fr = make_frame(L=L, H=H, seed=seed)
     cfg = default_config(compat=compat, adaptive=0)
-    lib = hip.lib()
-    lib.rslam_debug_set_sweep_exp.argtypes = [C.c_int]
     out = {}
     for mask in (0, 8, 4):
-        lib.rslam_debug_set_sweep_exp(mask)
+        hip_dbg.set_sweep_exp(mask)
         try:
-            g = hip.RslamHip(cfg)
+            g = hip_dbg.RslamHip(cfg)
             _, vis, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
             ic = (fr.ic & vis).astype(np.uint8)
             out[mask] = g.ransac_update(fr.z, ic, fr.draws)
             g.close()
         finally:
-            lib.rslam_debug_set_sweep_exp(-1)
+            hip_dbg.set_sweep_exp(-1)
     a, b, c = out[8], out[4], out[0]
     if n_li is not None:
         assert int(b["li"].sum()) == n_li          # the frame still exercises the route it was picked for

@@ -30,7 +30,7 @@ def hip():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device (the product path has no CPU fallback)")
     from ransac_slam_amd import api
-    api.lib()
+    api.lib(debug=True)            # the residual / distortion probes live in the diagnostic variant of the library
     return api
 
 
@@ -42,7 +42,7 @@ def both_residuals(hip, oracle_lib, fr, cfg):
     ic = (fr.ic & v0).astype(np.uint8)
     o.ransac_update(fr.z, ic, fr.draws)
     r_or = o.residuals()
-    g = hip.RslamHip(cfg)
+    g = hip.RslamHip(cfg, debug=True)
     g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
     g.step_frame(False); g.sync()
     r2_dev = g.debug_score_residuals()
@@ -60,10 +60,12 @@ def test_residuals_match_oracle_c3(hip, oracle_lib, compat):
     scored = ~np.isnan(r_or)
     assert scored.sum() >= 100 * r_or.shape[0]
     near = scored & (r_or < NEAR_PX)
-    if compat == 0:
-        assert near.sum() > 1000                       # the corrected arithmetic has real near-threshold pairs
+    # the corrected arithmetic has thousands of near-threshold pairs; with Q1 active (compat = 1: the angles are read from
+    # the position vector, Tracking.cpp:448) almost every pair projects far away and only the hypothesised feature itself
+    # and a handful of others land within 10 px -- still one pair per scored position, so the check below is never vacuous
+    assert near.sum() > (1000 if compat == 0 else r_or.shape[0] // 2), int(near.sum())
     d = np.abs(r2_dev[near] - r_or[near] ** 2)
-    assert d.size == 0 or d.max() <= RES_TOL, d.max()
+    assert d.max() <= RES_TOL, d.max()
     # (d) far pairs -- incl. the out-of-image projections that Q1 produces in compat mode, where neither 6 nor 10 Newton
     # steps need to have converged and the two values may differ: both sides must leave them far outside the threshold
     far = scored & ~near
