@@ -37,7 +37,7 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_bench_c3_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_bench_c3_pmc_summary.csv")
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -628,6 +628,23 @@ def main():
         out["dropin_ms_per_frame"] = {"value": float(np.median(t_drop[1:]) * 1e3),
                                       "note": "rslam_predict + rslam_ransac_update with pageable host buffers: "
                                               "26.3 MB of P up and down per frame; never the headline value"}
+        # the same with the caller's two covariance buffers page-locked by the library (rslam_config.reserved &
+        # RSLAM_PIN_HOST_COV: the binding of INTEGRATION.md 1.3, whose p_k_km1 / p_k_k are members that live as long as the filter)
+        cfg_pin = default_config(compat=args.compat, adaptive=0, dedup=args.dedup)
+        cfg_pin.reserved = 1
+        pctx = RslamHip(cfg_pin, device=local_rank)
+        P_in = np.asfortranarray(frame.P_pred, dtype=np.float64)
+        P_res = np.zeros((int(frame.n), int(frame.n)), order="F")
+        t_pin = []
+        for _ in range(8):
+            t0 = time.perf_counter()
+            pctx.predict(frame.types, frame.x_pred, P_in)
+            pctx.ransac_update(frame.z, ic, frame.draws, want_P=True, P_out=P_res)
+            t_pin.append(time.perf_counter() - t0)
+        pctx.close()
+        out["dropin_ms_per_frame"]["pinned_value"] = float(np.median(t_pin[2:]) * 1e3)
+        out["dropin_ms_per_frame"]["pinned_note"] = ("the same two calls with RSLAM_PIN_HOST_COV: the caller's p_k_km1 / p_k_k buffers are "
+                                                     "registered (hipHostRegister) on first use and reused every frame")
         # widened rows of SURVEY 8(f), timed beside their oracle restatements (host calls incl. transfers + sync)
         out["widened_rows"] = widened_rows(ctx, frame)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

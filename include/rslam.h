@@ -51,6 +51,7 @@ typedef struct rslam_camera {
     int32_t nRows, nCols;
 } rslam_camera;
 
+#define RSLAM_PIN_HOST_COV 1
 typedef struct rslam_config {
     rslam_camera cam;
     double  sigma_z;     /* RANSAC pixel threshold = std_z, Tracking.cpp:356            */
@@ -64,7 +65,13 @@ typedef struct rslam_config {
                             0 = evaluate exactly n_draws hypotheses (benchmark)         */
     int32_t dedup;       /* 1 = score each distinct hypothesised feature once and map
                             supports back (identical results, <= m hypotheses scored)   */
-    int32_t reserved;
+    int32_t reserved;    /* bit 0 (RSLAM_PIN_HOST_COV): page-lock the caller's covariance buffers.  The drop-in API
+                            (rslam_predict: P_pred, rslam_ransac_update / rslam_fetch_cov: P_new) then registers them with
+                            hipHostRegister on first use and keeps the registration while the same pointer comes back -- the
+                            reference reuses ExtendKF's members p_k_km1 / p_k_k frame after frame (ExtendKF.h:154-169) -- so
+                            the two 26 MB transfers of a frame run at the PCIe rate.  The caller promises that such a buffer
+                            stays allocated until another one has been passed or the context is destroyed (a buffer freed and
+                            re-allocated at the same address would still look registered); off by default for that reason */
 } rslam_config;
 
 /* State-vector layout: x = [r(3) q(4) v(3) w(3) | feature 0 | feature 1 | ...]

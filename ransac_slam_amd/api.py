@@ -278,13 +278,19 @@ class RslamHip:
         _chk(self._L.rslam_fetch_prior(self._h, _p(x), _p(P)), "rslam_fetch_prior")
         return x, P
 
-    def ransac_update(self, z, ic, draws, want_P=True):
+    def ransac_update(self, z, ic, draws, want_P=True, P_out=None):
+        """P_out: an (n, n) Fortran-ordered float64 array to receive p_k_k (reused frame after frame by a caller that asked
+        for page-locked covariance buffers: Config.reserved & 1)"""
         z = np.ascontiguousarray(z, dtype=np.float64)
         ic = np.ascontiguousarray(ic, dtype=np.uint8)
         draws = np.ascontiguousarray(draws, dtype=np.float64)
         self.H = len(draws)
         x_new = np.zeros(self.n)
-        P_new = np.zeros((self.n, self.n), order="F") if want_P else None
+        if want_P and P_out is not None:
+            assert P_out.shape == (self.n, self.n) and P_out.flags.f_contiguous and P_out.dtype == np.float64
+            P_new = P_out
+        else:
+            P_new = np.zeros((self.n, self.n), order="F") if want_P else None
         li = np.zeros(self.L, np.uint8)
         hi = np.zeros(self.L, np.uint8)
         bh, bs, he = C.c_int32(), C.c_int32(), C.c_int32()

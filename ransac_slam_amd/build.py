@@ -74,6 +74,34 @@ def build(force=False, verbose=False, debug=None, extra_flags=()):
     return LIB_DEBUG if debug else LIB
 
 
+DEV_DIR = os.path.join(HERE, "_dev")
+
+
+def build_dev(name, extra_flags=(), full=False):
+    """A kernel experiment as a library of its own, ransac_slam_amd/_dev/<name>.so: the diagnostic variant (-DRSLAM_DEBUG:
+    stamps, switches) with `extra_flags`, by default with the C3 shape of the persistent sweep only (-DRSLAM_DEV_ONLY_NJ12,
+    a third of the compile time).  For A/B measurements inside ONE gpurun call: RSLAM_HIP_LIB_DEBUG=<path> scripts/ab_frame.py --debug."""
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(DEV_DIR, exist_ok=True)
+    flags = ["-DRSLAM_DEBUG"] + ([] if full else ["-DRSLAM_DEV_ONLY_NJ12"]) + list(extra_flags)
+    objs = []
+    jobs = []
+    for src in SOURCES:
+        if src in ("kernels.hip", "rslam_api.hip"):
+            o = os.path.join(OBJ, "dev_%s_%s.o" % (name, os.path.splitext(src)[0]))
+            jobs.append([_hipcc()] + FLAGS + flags + ["-c", os.path.join(CSRC, src), "-o", o])
+        else:
+            if _obj_stale(src, True):
+                _compile((src, True, ()))
+            o = _obj_path(src, True)
+        objs.append(o)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    lib = os.path.join(DEV_DIR, name + ".so")
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
+
+
 HOST_DIR = os.path.join(HERE, "host")
 HOST_EXAMPLE = os.path.join(HOST_DIR, "track_frame_example")
 
@@ -107,6 +135,9 @@ def build_shard_example(force=False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "dev":          # python -m ransac_slam_amd.build dev <name> [-DFLAG ...]
+        print(build_dev(sys.argv[2], [a for a in sys.argv[3:] if a != "--full"], full="--full" in sys.argv))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host_example())
     print(build_shard_example())

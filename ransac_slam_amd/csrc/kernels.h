@@ -181,6 +181,9 @@ void launch_match(hipStream_t s, const Cam& cam, const uint8_t* image, const dou
 void launch_pred_patches(hipStream_t s, const Cam& cam, int compat, int L, const uint8_t* type, const int32_t* off,
                          const int32_t* xyz_src, const double* x, const double* h, const uint8_t* has_h,
                          const int32_t* slot, const double* rec, const float* rec_patch, double* out, int32_t* status);
+// dst (rows_dst x cols_dst, ld_dst) = src (rows_src x cols_src, ld_src), zero beyond the source: the change of leading
+// dimension of the covariance around a linear PCIe transfer (drop-in API)
+void launch_repitch(hipStream_t s, const double* src, long ld_src, double* dst, long ld_dst, int rows_src, int rows_dst, int cols_src, int cols_dst);
 int init_kernel_attributes();    // raise the dynamic-LDS limit of the MFMA kernels (80 KiB)
 int init_kernel_attributes2();
 void launch_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double* A, long lda,

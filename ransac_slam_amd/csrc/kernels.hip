@@ -293,53 +293,64 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
     }
     const int o = off[f];
     const double* Hf = H13 + 26 * (long)f;
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    // Two consecutive rows per thread: thirteen 16-byte loads in flight per lane (a column of P is a contiguous run of rows,
+    // NP is a multiple of 64 and every base is 16-byte aligned) and half as many waves to schedule for the same bytes -- the
+    // kernel is a latency chain (list entry -> layout -> columns) on top of a stream of 35.6 MB at C3.
+    const int row = 2 * (blockIdx.x * 256 + threadIdx.x);
     if (row >= NP) return;
     const int w = (type[f] == 0) ? 13 : 10;
-    double a0 = 0, a1 = 0;
-    double pv[13];
+    d2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
+    d2 pv[13];
     if (CAN_DEFER && da.flag && *da.flag != 0) {
         // P is the deferred P_li = J M J^T (DeferArgs): P_li H^T = J (M G^T) with M G^T = P_pred(:, cols) G^T - Y1 D^T; G = H J and
         // D = G Y1(cols, :) per feature come from the rescue prediction (da.Gd).  P_pred's columns are read as they are (it is
         // symmetric to rounding: an uploaded prior exactly, one left by rslam_ekf_prediction to ~1e-16 relative; the transposed
         // entries would be a strided gather per row); the tile workers of the HI pass symmetrise what they write.
         const double* gd = da.Gd + 34L * f;
-        const bool mix = blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < 7;      // state rows 3..6
-        double t1r[4] = {0.0, 0.0, 0.0, 0.0};
-        if (mix) {
+        // state rows 3..6 (J from the left): rows 2, 3 are thread 1's, 4, 5 thread 2's, 6, 7 thread 3's of the first row block
+        const bool first = blockIdx.x == 0 && threadIdx.x < 64;
+        double t1a[4] = {0.0, 0.0, 0.0, 0.0}, t1b[4] = {0.0, 0.0, 0.0, 0.0};      // rows of T1 for this thread's two state rows
+        if (first && threadIdx.x >= 1 && threadIdx.x <= 3) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t1r[q] = da.T1[(threadIdx.x - 3) + 4 * q];         // (requested with everything else)
+            for (int q = 0; q < 4; ++q) {
+                if (row >= 3 && row <= 6) t1a[q] = da.T1[(row - 3) + 4 * q];             // (requested with everything else)
+                if (row + 1 >= 3 && row + 1 <= 6) t1b[q] = da.T1[(row + 1 - 3) + 4 * q];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? da.Ppred[row + (long)col_index(o, k) * da.ldp] : 0.0;
-        double y[4];
+        for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? *reinterpret_cast<const d2*>(da.Ppred + row + (long)col_index(o, k) * da.ldp) : (d2){0.0, 0.0};
+        d2 y[4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) y[cc] = da.Y1[row + (long)cc * da.ldy];
+        for (int cc = 0; cc < 4; ++cc) y[cc] = *reinterpret_cast<const d2*>(da.Y1 + row + (long)cc * da.ldy);
 #pragma unroll
         for (int k = 0; k < 13; ++k) { a0 += pv[k] * gd[k]; a1 += pv[k] * gd[17 + k]; }
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) { a0 -= y[cc] * gd[13 + cc]; a1 -= y[cc] * gd[30 + cc]; }
-        // rows 3..6 of the result: J from the left (threads 3..6 of the first row block, one wave)
-        if (blockIdx.x == 0 && threadIdx.x < 64) {
-            const double p3 = __shfl(a0, 3), p4 = __shfl(a0, 4), p5 = __shfl(a0, 5), p6 = __shfl(a0, 6);
-            const double q3 = __shfl(a1, 3), q4 = __shfl(a1, 4), q5 = __shfl(a1, 5), q6 = __shfl(a1, 6);
-            if (mix) {
-                a0 = t1r[0] * p3 + t1r[1] * p4 + t1r[2] * p5 + t1r[3] * p6;
-                a1 = t1r[0] * q3 + t1r[1] * q4 + t1r[2] * q5 + t1r[3] * q6;
+        if (first) {
+            // rows 3, 4, 5, 6 of both result columns, as they stand before the mix
+            const double p3 = __shfl(a0.y, 1), p4 = __shfl(a0.x, 2), p5 = __shfl(a0.y, 2), p6 = __shfl(a0.x, 3);
+            const double q3 = __shfl(a1.y, 1), q4 = __shfl(a1.x, 2), q5 = __shfl(a1.y, 2), q6 = __shfl(a1.x, 3);
+            if (row >= 3 && row <= 6) {
+                a0.x = t1a[0] * p3 + t1a[1] * p4 + t1a[2] * p5 + t1a[3] * p6;
+                a1.x = t1a[0] * q3 + t1a[1] * q4 + t1a[2] * q5 + t1a[3] * q6;
+            }
+            if (row + 1 >= 3 && row + 1 <= 6) {
+                a0.y = t1b[0] * p3 + t1b[1] * p4 + t1b[2] * p5 + t1b[3] * p6;
+                a1.y = t1b[0] * q3 + t1b[1] * q4 + t1b[2] * q5 + t1b[3] * q6;
             }
         }
-        out[row + (long)(2 * c) * ldo] = a0;
-        out[row + (long)(2 * c + 1) * ldo] = a1;
+        *reinterpret_cast<d2*>(out + row + (long)(2 * c) * ldo) = a0;
+        *reinterpret_cast<d2*>(out + row + (long)(2 * c + 1) * ldo) = a1;
         return;
     }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? P[row + (long)col_index(o, k) * NP] : 0.0;     // all thirteen in flight at once
+    for (int k = 0; k < 13; ++k) pv[k] = (k < w) ? *reinterpret_cast<const d2*>(P + row + (long)col_index(o, k) * NP) : (d2){0.0, 0.0};     // all thirteen in flight at once
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         if (k < w) { a0 += pv[k] * Hf[k]; a1 += pv[k] * Hf[13 + k]; }
     }
-    out[row + (long)(2 * c) * ldo] = a0;
-    out[row + (long)(2 * c + 1) * ldo] = a1;
+    *reinterpret_cast<d2*>(out + row + (long)(2 * c) * ldo) = a0;
+    *reinterpret_cast<d2*>(out + row + (long)(2 * c + 1) * ldo) = a1;
 }
 
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
@@ -352,7 +363,7 @@ void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int
     InnovArgs iv{S, z, h, has_h, wv, status, x, ith, iph, sc};
     DeferArgs da{}; if (defer) da = *defer;
     GateList g{}; if (gl && defer) g = *gl;
-    const dim3 grid(NP / 256 + (NP % 256 ? 1 : 0), max_count);
+    const dim3 grid(NP / 512 + (NP % 512 ? 1 : 0), max_count);          // two rows per thread
     if (defer) pht_kernel<true><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da, g);
     else pht_kernel<false><<<grid, dim3(256), 0, s>>>(P, NP, list, max_count, d_count, H13, off, type, out, ldo, iv, da, g);
 }
@@ -920,6 +931,13 @@ __device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_i
 // s_waitcnt vmcnt(0) lgkmcnt(0): a wait for the LDS round trip on the publishing side (on the panel wave: on the chain) and,
 // worse, for every outstanding GLOBAL access of the wave -- the T waves of the persistent sweep keep hand-over polls and
 // operand loads in flight across pivot steps, and each such wait stalled their step, and with it the chain, for a memory latency.
+// INVARIANT of the fence-free form: everything that cd_post publishes has been written with plain ds_write by the posting
+// wave itself.  An operand staged by LDS-DMA (global_load ... lds, tracked by vmcnt, not ordered with ds_write) in front of a
+// cd_post would race silently -- no such transfer feeds this pipeline (the tile engine's DMA buffers are never handed over
+// through cd_post).  The in-order argument is a property of the gfx950 LDS path: other targets take the fenced form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(CD_HW_FENCES)
+#error "cd_post / cd_wait without hardware fences are validated on gfx950 only: build other targets with -DCD_HW_FENCES"
+#endif
 __device__ __forceinline__ void cd_post(CdShared& sh, int flag, int value)
 {
 #if defined(CD_HW_FENCES)
@@ -3100,13 +3118,15 @@ int init_kernel_attributes()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(trail_stream2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
+#if !defined(RSLAM_DEV_ONLY_NJ12)      // (development builds of kernel experiments instantiate the C3 shape only: a third of the compile time)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+#endif
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persistent_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
@@ -3168,6 +3188,9 @@ bool sweep_persistent_eligible(const SystemDims& d)
 {
     static const bool off = debug_env("RSLAM_SWEEP_STEPS");       // measurement: the one-launch-per-step sequence
     if (off || d.RP <= 0) return false;
+#if defined(RSLAM_DEV_ONLY_NJ12)
+    if (d.RP / 64 > 12) return false;
+#endif
     return d.RP / 64 <= 16 && 1 + d.ldA / 16 <= device_cus();
 }
 
@@ -3209,10 +3232,14 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
         int32_t* fl_cur = flags + set * SWEEP_FLAG_INTS;
         int32_t* fl_other = flags + (1 - set) * SWEEP_FLAG_INTS;
 #define SWP_LAUNCH(NJ) sweep_persistent_kernel<NJ><<<grid, block, SWP_LDS_BYTES, s>>>(A, d.ldA, sel, slot_nblk, slot_k, rp_blocks, d.NP, *src, Linv, Ystore, fl_cur, fl_other, status_sel, stamp_this ? sweep_dbg_buffer() : nullptr, exp_mask, wa)
+#if defined(RSLAM_DEV_ONLY_NJ12)
+        SWP_LAUNCH(12);
+#else
         if (rp_blocks <= 4) SWP_LAUNCH(4);
         else if (rp_blocks <= 8) SWP_LAUNCH(8);
         else if (rp_blocks <= 12) SWP_LAUNCH(12);
         else SWP_LAUNCH(16);
+#endif
 #undef SWP_LAUNCH
         return Ystore;
     }
@@ -3821,6 +3848,26 @@ int init_kernel_attributes2()
         fprintf(stderr, "[rslam] rank_update_kernel: %d workgroups per CU at %d B of dynamic LDS\n", nb, bytes);
     }
     return (int)e;
+}
+
+// ---------------------------------------------------------------------------
+// Drop-in API: the covariance crosses PCIe as ONE linear transfer of the caller's n x n matrix (a pitched 2-D copy of 1813
+// columns of 14.5 KB each runs at a fraction of the link rate); the change of leading dimension n <-> NP and the zero
+// padding happen on the device, at HBM speed.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+repitch_kernel(const double* __restrict__ src, long lds_, double* __restrict__ dst, long ldd, int rows_src, int rows_dst, int cols_src)
+{
+    // one column of the destination per blockIdx.y; rows beyond the source's (and columns beyond it) are zero
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows_dst; r += gridDim.x * 256)
+        dst[r + (long)c * ldd] = (r < rows_src && c < cols_src) ? src[r + (long)c * lds_] : 0.0;
+}
+
+void launch_repitch(hipStream_t s, const double* src, long ld_src, double* dst, long ld_dst, int rows_src, int rows_dst, int cols_src, int cols_dst)
+{
+    if (rows_dst <= 0 || cols_dst <= 0) return;
+    repitch_kernel<<<dim3((rows_dst + 255) / 256 > 8 ? 8 : (rows_dst + 255) / 256, cols_dst), dim3(256), 0, s>>>(src, ld_src, dst, ld_dst, rows_src, rows_dst, cols_src);
 }
 
 // ---------------------------------------------------------------------------

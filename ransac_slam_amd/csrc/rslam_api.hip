@@ -75,6 +75,7 @@ struct rslam_ctx {
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Y, d_Linv,
                    d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr, d_sc, d_Y1, d_Gd;
     DevBuf<uint8_t> d_image;
+    DevBuf<double> d_stage;               // drop-in API: the caller's n x n covariance as it crosses PCIe (one linear transfer)
     // feature store: initialisation records of Map::initialize_a_features (Map.cpp:286-292), one slot per feature
     DevBuf<double> d_rec;                 // slot * 14: uv(2) R(9 col-major) r(3)
     DevBuf<float> d_rec_patch;            // slot * 1681: patch_when_initialized as float32, row-major 41 x 41
@@ -110,6 +111,9 @@ struct rslam_ctx {
     int k10_reruns = 0;
     int k10_inject = 0;                // fault injection (diagnostic variant of the library only)
     void* checked_comm = nullptr;      // rslam_shard_frame: the communicator whose size / rank have been checked
+    // drop-in API: the caller's covariance buffers (p_k_km1 in, p_k_k out) are page-locked on first use so that the two
+    // 26 MB transfers of a frame run at the PCIe rate instead of through the runtime's pageable staging
+    struct HostReg { const void* p = nullptr; size_t bytes = 0; bool ok = false; } reg_in, reg_out;
     int rep_status = 0, rep_front = 0, rep_sticky = 0;   // status words of the frame in flight once read_status has taken them off the device
     bool frame_checked = true;         // read_status has (not) looked at the update stage in flight yet
 };
@@ -238,8 +242,10 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
     c->d_sup_local.release(); c->d_sup_all.release();
-    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
+    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
+    if (c->reg_in.ok) (void)hipHostUnregister(const_cast<void*>(c->reg_in.p));
+    if (c->reg_out.ok) (void)hipHostUnregister(const_cast<void*>(c->reg_out.p));
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -298,6 +304,20 @@ static int set_layout(rslam_ctx* c, const rslam_layout* lay)
     return RSLAM_OK;
 }
 
+// Page-lock a caller buffer the drop-in API moves every frame (same pointer and size as last time: nothing to do).  A
+// registration that fails -- the caller has pinned it already, the range is not registrable -- is not an error: the copy
+// then takes the pageable path as before.  Only when the caller asked for it (rslam_config.reserved & RSLAM_PIN_HOST_COV:
+// it promises the buffers' lifetime, include/rslam.h).
+static void pin_host_buffer(rslam_ctx* c, rslam_ctx::HostReg& r, const void* p, size_t bytes)
+{
+    if (!(c->cfg.reserved & RSLAM_PIN_HOST_COV)) return;
+    if (r.p == p && r.bytes == bytes) return;
+    if (r.ok) (void)hipHostUnregister(const_cast<void*>(r.p));
+    r.p = p; r.bytes = bytes;
+    r.ok = (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess);
+    if (!r.ok) (void)hipGetLastError();               // (leave no sticky error behind)
+}
+
 // host (x, P) -> padded device buffers
 static int upload_xp(rslam_ctx* c, const double* x, const double* P, double* d_x, double* d_Pm)
 {
@@ -305,8 +325,16 @@ static int upload_xp(rslam_ctx* c, const double* x, const double* P, double* d_x
     const int n = c->n, NP = c->NP;
     HIPCHK(hipMemsetAsync(d_x, 0, sizeof(double) * NP, s));
     HIPCHK(hipMemcpyAsync(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
-    if (NP != n) HIPCHK(hipMemsetAsync(d_Pm, 0, sizeof(double) * (size_t)NP * NP, s));
-    HIPCHK(hipMemcpy2DAsync(d_Pm, sizeof(double) * NP, P, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, s));
+    pin_host_buffer(c, c->reg_in, P, sizeof(double) * (size_t)n * n);
+    if (NP != n) {
+        // one linear transfer, then the leading dimension n -> NP and the zero padding on the device
+        if (c->d_stage.ensure((size_t)n * n) < 0) return RSLAM_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(c->d_stage.p, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+        launch_repitch(s, c->d_stage.p, n, d_Pm, NP, n, NP, n, NP);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(d_Pm, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
     return RSLAM_OK;
 }
@@ -1116,8 +1144,15 @@ extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
     if (!c || !P) return RSLAM_ERR_ARG;
     const int rc = settle_posterior(c);          // RSLAM_ERR_STATE unless a posterior exists
     if (rc) return rc;
-    HIPCHK(hipMemcpy2DAsync(P, sizeof(double) * c->n, c->d_P.p, sizeof(double) * c->NP, sizeof(double) * c->n, c->n,
-                            hipMemcpyDeviceToHost, c->stream));
+    pin_host_buffer(c, c->reg_out, P, sizeof(double) * (size_t)c->n * c->n);
+    if (c->NP != c->n) {
+        if (c->d_stage.ensure((size_t)c->n * c->n) < 0) return RSLAM_ERR_HIP;
+        launch_repitch(c->stream, c->d_P.p, c->NP, c->d_stage.p, c->n, c->n, c->n, c->n, c->n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(P, c->d_stage.p, sizeof(double) * (size_t)c->n * c->n, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(P, c->d_P.p, sizeof(double) * (size_t)c->n * c->n, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return RSLAM_OK;
 }

@@ -81,7 +81,11 @@ public:
 
     // n_draws: length of the draw list handed to the RANSAC loop per frame (>= the
     // reference's initial n_hyp = 1000, Tracking.cpp:357)
-    ExtendKF(CamParam* param, int device = 0, int compat = 1, int n_draws = 1400)
+    // pin_covariance: page-lock p_k_km1 / p_k_k for the transfers of the drop-in calls (RSLAM_PIN_HOST_COV, include/rslam.h);
+    // the two matrices are members of this object, so they outlive every call -- but a resize (Map::map_management adds or
+    // deletes a feature) re-allocates them: the registration follows the new pointer / size, and a caller that resizes back to
+    // an earlier size must not rely on pinning (a re-allocation at the same address would still look registered)
+    ExtendKF(CamParam* param, int device = 0, int compat = 1, int n_draws = 1400, bool pin_covariance = false)
         : cam(param), n_draws_(n_draws)
     {
         rslam_config cfg{};
@@ -90,6 +94,7 @@ public:
         cfg.cam.nRows = param->nRows; cfg.cam.nCols = param->nCols;
         cfg.sigma_z = std_z; cfg.p_success = 0.99; cfg.n_hyp_init = 1000; cfg.chi2_gate = 5.9915;
         cfg.compat = compat; cfg.adaptive = 1; cfg.dedup = 1;
+        cfg.reserved = pin_covariance ? RSLAM_PIN_HOST_COV : 0;
         const int rc = rslam_create(&cfg, device, &ctx_);
         if (rc) throw Error(rc, "rslam_create");
     }

@@ -287,3 +287,30 @@ def test_sequence_of_measurements_on_resident_prior(hip, oracle_lib, compat):
     if not os.environ.get("RSLAM_SWEEP_STEPS"):          # (the launch-per-step sweep, kept for measurement, re-captures by design)
         assert c1["graph_captures"] == c0["graph_captures"] and c1["sweep_reruns"] == 0
     g.close()
+
+
+# --------------------------------------------------------------------------- drop-in API with page-locked caller buffers
+def test_dropin_with_pinned_covariance_buffers(hip):
+    """RSLAM_PIN_HOST_COV (rslam_config.reserved bit 0): the caller's p_k_km1 / p_k_k buffers are registered on first use and
+    reused; the results must be bit-identical to the pageable path, frame after frame, also when a buffer's CONTENT changes
+    (the registration is of the pages, not of a snapshot)."""
+    fr = make_frame(L=120, H=200, seed=905)
+    cfg0 = default_config(compat=0, adaptive=1)
+    cfg1 = default_config(compat=0, adaptive=1); cfg1.reserved = 1
+    g0, g1 = hip.RslamHip(cfg0), hip.RslamHip(cfg1)
+    P_in = np.asfortranarray(fr.P_pred, dtype=np.float64).copy(order="F")
+    P_out = np.zeros((fr.n, fr.n), order="F")
+    for k in range(3):
+        if k == 2:
+            P_in *= 1.5                                   # same buffer, new content
+        _, vis, _ = g0.predict(fr.types, fr.x_pred, P_in.copy(order="F"))
+        ic = (fr.ic & vis).astype(np.uint8)
+        r0 = g0.ransac_update(fr.z, ic, fr.draws)
+        g1.predict(fr.types, fr.x_pred, P_in)
+        r1 = g1.ransac_update(fr.z, ic, fr.draws, P_out=P_out)
+        assert r1["P_new"] is P_out
+        for key in ("best_hyp", "best_support", "hyps_evaluated"):
+            assert r1[key] == r0[key]
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+        assert np.array_equal(r1["x_new"], r0["x_new"]) and np.array_equal(P_out, r0["P_new"])
+    g0.close(); g1.close()

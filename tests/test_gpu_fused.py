@@ -246,6 +246,38 @@ def test_deferred_li_covariance_equals_immediate(hip_dbg, oracle_lib, L, H, seed
     assert close_P(out[0]["P_new"], out[512]["P_new"], 1e-11) and close_x(out[0]["x_new"], out[512]["x_new"], 1e-12)
 
 
+def test_deferred_li_covariance_with_asymmetric_prior(hip_dbg, oracle_lib):
+    """The invariant the deferred route leans on: a prior is symmetric to rounding (an uploaded p_k_km1 exactly, one left by
+    rslam_ekf_prediction to ~1e-16 relative).  Its readers do not all symmetrise the same way -- the second P H^T reads raw
+    columns of P_pred, the tile workers sym(P_pred) -- so an asymmetry of relative size e moves the deferred result by O(e)
+    against the immediate stream: with e = 1e-12 both must still be within the parity tolerance of the oracle run on the
+    symmetrised prior, and of each other to ~1e-10 (nothing amplifies the asymmetry)."""
+    fr = make_frame(L=90, H=120, seed=21)
+    cfg = default_config(compat=1, adaptive=0)
+    P = np.asarray(fr.P_pred).copy()
+    rng = np.random.default_rng(17)
+    P_as = P * (1.0 + 1e-12 * rng.standard_normal(P.shape))              # entry-wise relative asymmetry ~1e-12
+    assert np.max(np.abs(P_as - P_as.T)) > 0
+    fr_sym = make_frame(L=90, H=120, seed=21)
+    fr_sym.P_pred = 0.5 * (P_as + P_as.T)
+    ic, r0 = oracle_frame(oracle_lib, fr_sym, cfg)
+    assert int(r0["li"].sum()) in (1, 2)
+    out = {}
+    for mask in (0, 512):
+        hip_dbg.set_sweep_exp(mask)
+        try:
+            g = hip_dbg.RslamHip(cfg)
+            g.predict(fr.types, fr.x_pred, P_as)
+            out[mask] = g.ransac_update(fr.z, ic, fr.draws)
+            g.close()
+        finally:
+            hip_dbg.set_sweep_exp(-1)
+        r1 = out[mask]
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"]), mask
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"]), mask
+    assert close_P(out[0]["P_new"], out[512]["P_new"], 1e-10) and close_x(out[0]["x_new"], out[512]["x_new"], 1e-10)
+
+
 def test_deferred_li_covariance_without_hi_inliers(hip, oracle_lib):
     """... and when the rescue gate lets nobody through (chi-square gate at ~0) the high-innovation pass is a pass-through of
     a covariance that does not exist yet: it has to be written then (wk_materialise_deferred)."""

@@ -109,6 +109,47 @@ def test_add_feature(hip, oracle_lib, case):
     g.close()
 
 
+def test_widened_rows_at_c5_size(hip, oracle_lib):
+    """The rows either side of the hot path at the size of BASELINE's stress configuration (1000 landmarks, n = 6013; the
+    other cases stop at 300): ekf_prediction, one insertion (n + 6), one deletion -- each against the oracle on the same state."""
+    cam = default_camera()
+    fr = make_frame(L=1000, H=2, seed=704)
+    x, P = fr.x_pred.copy(), np.asarray(fr.P_pred)
+    assert fr.n == 6013
+    x[10:13] += [0.02, -0.01, 0.03]; x[7:10] += [0.1, 0.0, -0.2]
+    g = hip.RslamHip(default_config())
+    # ExtendKF::ekf_prediction (ExtendKF.cpp:333-388)
+    xp0, Pp0 = oracle_lib.ekf_prediction(x, P, 1.0, 0.007, 0.007)
+    g.set_posterior(fr.types, x, P)
+    g.ekf_prediction(1.0, 0.007, 0.007)
+    xp1, Pp1 = g.fetch_prior()
+    assert np.array_equal(xp1[13:], x[13:]) and np.array_equal(Pp1[13:, 13:], P[13:, 13:])
+    assert np.allclose(xp1, xp0, rtol=1e-13, atol=1e-15)
+    assert np.max(np.abs(Pp1 - Pp0)) <= 1e-13 * np.abs(Pp0).max()
+    del xp0, Pp0, xp1, Pp1
+    # Map::add_a_feature_covariance_inverse_depth (Map.cpp:339-400), then Map::delete_a_feature (Map.cpp:69-104)
+    g.set_posterior(fr.types, x, P)
+    uvd = [150.0, 110.0]
+    x0, P0 = oracle_lib.map_add_feature(cam, 1.0, x, P, np.array(uvd), 1.0, 1.0)
+    g.map_add_feature(uvd, 1.0, 1.0)
+    t1 = np.append(fr.types, 0).astype(np.uint8)
+    n, types, offs = g.get_layout()
+    assert n == fr.n + 6 and np.array_equal(types, t1) and np.array_equal(offs, _offsets(t1))
+    x1, P1 = g.fetch_posterior()
+    assert np.allclose(x1, x0, rtol=1e-13, atol=1e-15) and _close(P1, P0)
+    assert np.array_equal(P1[:fr.n, :fr.n], P)
+    f = fr.L // 2
+    x0d, P0d = oracle_lib.map_delete_feature(t1, x1, P1, f)            # (on the device's own state: the deletion is bit-exact)
+    del x0, P0
+    g.map_delete_feature(f)
+    n2, types2, offs2 = g.get_layout()
+    t2 = np.delete(t1, f)
+    assert n2 == fr.n and np.array_equal(types2, t2) and np.array_equal(offs2, _offsets(t2))
+    x2, P2 = g.fetch_posterior()
+    assert np.array_equal(x2, x0d) and np.array_equal(P2, P0d)
+    g.close()
+
+
 def test_map_predict_matches_oracle(hip, oracle_lib):
     fr = make_frame(L=60, H=2, seed=711, frac_cartesian=0.3)
     cfg = default_config()

@@ -98,7 +98,7 @@ def test_distort_fm_score_kat(hip, oracle_lib):
     """distort_fm_score (6 steps, raw reciprocal slopes) against ExtendKF::distort_fm (10 steps, divisions) as the oracle and
     the device evaluate it, over the whole image: centre, a dense radial sweep out to the corners and the exact corners."""
     cam = default_camera()
-    g = hip.RslamHip(default_config())
+    g = hip.RslamHip(default_config(), debug=True)
     rng = np.random.default_rng(5)
     pts = [[cam.Cx, cam.Cy], [0.0, 0.0], [cam.nCols - 1.0, 0.0], [0.0, cam.nRows - 1.0], [cam.nCols - 1.0, cam.nRows - 1.0],
            [cam.nCols, cam.nRows], [-0.5, -0.5]]
@@ -125,7 +125,7 @@ def test_far_projections_take_the_reference_sequence(hip, oracle_lib):
     to rounding (the same source inlined at two places: the compiler contracts multiply-adds differently), and with the
     oracle's distort_fm."""
     cam = default_camera()
-    g = hip.RslamHip(default_config())
+    g = hip.RslamHip(default_config(), debug=True)
     rng = np.random.default_rng(6)
     corner = float(np.hypot(cam.nCols - cam.Cx, cam.nRows - cam.Cy))
     ang = rng.uniform(0, 2 * np.pi, 6000)
