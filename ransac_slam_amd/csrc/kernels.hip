@@ -889,8 +889,33 @@ struct CdShared {
     int timeout;
 };
 
-#if defined(CD_STAMPS)   // diagnostic build: where do the cycles of a pivot step go (never in the product build)
+#if defined(CD_STAMPS) || defined(CD_SPINS)
 __device__ unsigned long long g_cd_stamps[16];
+#endif
+// CD_SPINS: non-intrusive view of who waits for whom in the pivot pipeline -- polls that found their flag not yet up, counted in
+// registers and added to g_cd_stamps once per diagonal block: [0] extra looks of the panel wave, [1] its steps, [2] polls of T
+// wave 0's wait for the panel, [3] its steps, [4] / [5] M wave 0, [6] / [7] inverse wave
+#if defined(CD_SPINS)
+#define CD_SPIN_ADD(slot, v) atomicAdd(&g_cd_stamps[slot], (unsigned long long)(v))
+#else
+#define CD_SPIN_ADD(slot, v)
+#endif
+// CD_TIMELINE: shader-clock time line of the pivot pipeline, [who][block & 7][step][slot]: who 0 = panel wave (slots: first
+// look issued, flags up + data landed, panel posted), who 1 = T wave 0 (step begins, panel flag seen, operands landed, strip
+// posted); written with fire-and-forget global stores by lane 0; each stamp drains the wave's LDS queue (~60 cycles).
+#if defined(CD_TIMELINE)
+__device__ unsigned long long g_cd_log[2][8][16][4];
+#define CD_TL(who, blk, step, slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                                         if ((threadIdx.x & 63) == 0) g_cd_log[who][(blk) & 7][step][slot] = t_; } while (0)
+#else
+#define CD_TL(who, blk, step, slot)
+#endif
+#if defined(CD_TL_M)
+#define CD_TL_M_ON 1
+#else
+#define CD_TL_M_ON 0
+#endif
+#if defined(CD_STAMPS)   // diagnostic build: where do the cycles of a pivot step go (never in the product build)
 #define CD_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #define CD_ACC_T(slot, a, b, tid) do { if (threadIdx.x == (tid)) g_cd_stamps[slot] += (b) - (a); } while (0)
 #define CD_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
@@ -904,7 +929,7 @@ __device__ unsigned long long g_cd_stamps[16];
 // every M-wave flag >= need_m; wave-uniform, bounded so that a logic error ends in an error
 // code instead of a hung queue
 template <int SLEEP>
-__device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_inv, int need_t, int need_m)
+__device__ __forceinline__ int cd_wait(CdShared& sh, int need_panel, int need_inv, int need_t, int need_m)
 {
     const int li = threadIdx.x & 15;
     const int need = li == 0 ? need_panel : li == 1 ? need_inv : li < 2 + CD_TW ? need_t : li < 2 + CD_TW + CD_MW ? need_m : -(1 << 30);
@@ -922,6 +947,7 @@ __device__ __forceinline__ void cd_wait(CdShared& sh, int need_panel, int need_i
 #else
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
 #endif
+    return spins;
 }
 
 // Publish: what this wave wrote to LDS, then the flag.  Everything handed over between the waves of the pipeline lives in
@@ -971,11 +997,13 @@ __device__ constexpr int cd_tc(int idx) { return idx - (idx < 1 ? 0 : idx < 3 ? 
 
 // Panel wave: the pivot chain.  KEEP_L = false: L itself is not collected (persistent sweep: nobody reads it).
 template <bool KEEP_L = true>
-__device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
+__device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4, int blk = 0)
 {
     const int l = threadIdx.x & 63;
     __builtin_amdgcn_s_setprio(3);                          // the chain wins every issue arbitration on its SIMD
     double xp0 = 0.0, xp1 = 0.0, xp2 = 0.0, xp3 = 0.0;     // own row of the previous panel
+    int dbg_looks = 0, dbg_steps = 0;
+    struct SpinOut { int& a; int& b; __device__ ~SpinOut() { if ((threadIdx.x & 63) == 0) { CD_SPIN_ADD(0, a); CD_SPIN_ADD(1, b); } } } spin_out{dbg_looks, dbg_steps};
     // flag li must reach s + need_off: T waves s, inverse wave and M waves s - 1, nothing else
     const int need_off = ((threadIdx.x & 15) >= 2 && (threadIdx.x & 15) < 2 + CD_TW) ? 0
                        : ((threadIdx.x & 15) == 1 || ((threadIdx.x & 15) >= 2 + CD_TW && (threadIdx.x & 15) < 2 + CD_TW + CD_MW)) ? -1 : -(1 << 30);
@@ -998,24 +1026,62 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
             {
                 const int li = threadIdx.x & 15;
                 const int need = s + need_off;
+                // (these sixteen u values are what lanes p0..p0+3 of THIS wave hold in xp0..xp3; taking them by readlane --
+                //  32 v_readlane_b32 under the latency of the other reads -- measured 1 us per block SLOWER than the broadcast
+                //  LDS reads: the chain is bound by the number of instructions this wave issues)
+                int v;
+#define CD_PANEL_LOADS() do {                                                                                              \
+                    v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                  \
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);    /* compiler: keep the data reads behind the flag read */     \
+                    a0 = Tc[l]; a1 = Tc[64 + l]; a2 = Tc[128 + l]; a3 = Tc[192 + l];                                       \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+                        _Pragma("unroll") for (int k = 0; k < 4; ++k) u[4 * j + k] = Xp[j * 64 + p0 + k];                    \
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                               \
+                } while (0)
+                CD_TL(0, blk, s, 0);
+#if !defined(CD_NO_PEEL_POLL)
+                // The first look is straight-line code: a loop header would carry the s_waitcnt lgkmcnt(0) its back edge needs
+                // (the re-issued reads write the same registers), i.e. a wait for this wave's own panel stores of the step
+                // before, on the chain, in every step.  Only a flag that is not up yet enters the polling loop.
+                CD_PANEL_LOADS();
+                ++dbg_steps;
+                if (!__all(v >= need)) {
+#if defined(CD_POLL_ALL)
+                    int spins = 0;
+                    while (true) {
+                        CD_PANEL_LOADS();
+                        ++dbg_looks;
+                        if (__all(v >= need)) break;
+                        if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                    }
+#else
+                    // not up yet: poll the flags ALONE (one 4-byte read per look), then read the data once more.  Every look
+                    // that re-reads the whole batch moves 10 KB through the LDS pipe, and the counters of a -DCD_SPINS build
+                    // say the first look fails in most steps, three to four times in a row: 30-40 KB per step of traffic
+                    // that delays the LDS reads of the very waves the chain is waiting for.
+                    int spins = 0;
+                    while (true) {
+                        v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++dbg_looks;
+                        if (__all(v >= need)) break;
+                        if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                    }
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    CD_PANEL_LOADS();
+#endif
+                }
+#else
                 int spins = 0;
                 while (true) {
-                    const int v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);             // compiler: keep the data reads behind the flag read
-                    a0 = Tc[l]; a1 = Tc[64 + l]; a2 = Tc[128 + l]; a3 = Tc[192 + l];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) u[4 * j + k] = Xp[j * 64 + p0 + k];
-                    // (these sixteen values are what lanes p0..p0+3 of THIS wave hold in xp0..xp3; taking them by readlane --
-                    //  32 v_readlane_b32 under the latency of the other reads -- measured 1 us per block SLOWER than the broadcast
-                    //  LDS reads: the chain is bound by the number of instructions this wave issues)
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    CD_PANEL_LOADS();
                     if (__all(v >= need)) break;
                     if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
                 }
+#endif
+#undef CD_PANEL_LOADS
             }
             CD_STAMP(s1);
+            CD_TL(0, blk, s, 1);
             __builtin_amdgcn_sched_barrier(0);
             // strip row l: T(l, p0+k) -= sum_j X_prev(l, j) X_prev(p0+k, j)
             a0 = fma(-xp0, u[0], a0); a1 = fma(-xp0, u[1], a1); a2 = fma(-xp0, u[2], a2); a3 = fma(-xp0, u[3], a3);
@@ -1049,6 +1115,7 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
             if (l == 0) { double* R = sh.Rs[q & 1]; R[0] = r0; R[1] = r1; R[2] = r2; R[3] = r3; }
             CD_STAMP(sd);
             cd_post(sh, 0, s + 1);
+            CD_TL(0, blk, s, 2);
             CD_STAMP(s2);
             CD_ACC_T(0, s0, s1, 0); CD_ACC_T(1, s1, sa, 0); CD_ACC_T(5, sa, sc, 0); CD_ACC_T(7, sc, sd, 0); CD_ACC_T(2, sd, s2, 0);
             CD_ACC_T(6, s0, s2, 0);
@@ -1056,23 +1123,53 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4)
     }
 }
 
+// 16-byte write-through store (agent scope: served by the memory side, see "Memory protocol" of the persistent sweep)
+__device__ __forceinline__ void st_coh2(double* p, double a, double b)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+
+// What the inverse wave of the persistent sweep does with its rows of L^-1 besides collecting them in LDS (CdInvOut::Lglob
+// != nullptr): it writes them to global memory AS THEY BECOME FINAL, one pivot step behind the chain (write-through stores,
+// never waited for inside the loop), and posts the flag the strips wait for itself, right after its last step -- the
+// strips learn of L^-1(k) ~0.3 us after the chain of block k has ended instead of ~2.5 us (stores at the top of the next
+// block, X product, barrier, flag), so their hand-over of the next row block reaches the chain workgroup early in its
+// chain instead of late, and the sweep's last solve starts that much earlier behind the last block.
+struct CdInvOut {
+    double* Lglob;            // L^-1(k): [row + 64 col], lower triangle, identity beyond the rows that exist
+    int32_t* flag; int value; // *flag = value once every row has reached memory
+};
+
 // Inverse wave: pivot rows of the running inverse, one block behind the panel wave.  Returns (CHECK only) whether a
 // pivot was not a positive finite number: where L is not collected this wave, which is off the chain, looks at the
 // reciprocal square roots the panel wave publishes.
 template <bool CHECK = false>
-__device__ __forceinline__ bool cd_inverse_wave(CdShared& sh, int n_piv4)
+__device__ __forceinline__ bool cd_inverse_wave(CdShared& sh, int n_piv4, const CdInvOut io = CdInvOut{nullptr, nullptr, 0})
 {
     const int l = threadIdx.x & 63;
     bool bad = false;
     double mp0 = 0.0, mp1 = 0.0, mp2 = 0.0, mp3 = 0.0;     // own column of Ms of the previous block
+    if (io.Lglob && n_piv4 < 16) {
+        // a last block of fewer than 64 rows: identity beyond the pivots that exist (column l: rows 4 n_piv4 .. 63)
+        for (int row = 4 * n_piv4; row < 64; row += 2) st_coh2(io.Lglob + row + 64 * l, row == l ? 1.0 : 0.0, row + 1 == l ? 1.0 : 0.0);
+    }
+    auto finish = [&]() {
+        if (io.Lglob) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0) __hip_atomic_store(io.flag, io.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 #pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int s = 4 * sb + q;                     // block
             const int p0 = 16 * sb + 4 * q;
-            if (s >= n_piv4) return bad;
-            cd_wait<1>(sh, s + 1, 0, 0, s + 1);           // panel s (L4, reciprocals); strip of block s (M waves, iteration s)
+            if (s >= n_piv4) { finish(); return bad; }
+            { const int sp = cd_wait<1>(sh, s + 1, 0, 0, s + 1);           // panel s (L4, reciprocals); strip of block s (M waves, iteration s)
+              if (l == 0) { CD_SPIN_ADD(6, sp); CD_SPIN_ADD(7, 1); } (void)sp; }
             const double* Mc = sh.Mst[q & 1];
             const double* Xp = sh.Xs[(q + 3) & 3];        // panel s-1
             const double* Xc = sh.Xs[q];                  // panel s: rows p0..p0+3 are L4
@@ -1107,8 +1204,11 @@ __device__ __forceinline__ bool cd_inverse_wave(CdShared& sh, int n_piv4)
             sh.Mf[l * CD_LD + p0 + 0] = mp0; sh.Mf[l * CD_LD + p0 + 1] = mp1;
             sh.Mf[l * CD_LD + p0 + 2] = mp2; sh.Mf[l * CD_LD + p0 + 3] = mp3;
             cd_post(sh, 1, s + 1);
+            // (entries right of the diagonal are exact zeros: the running inverse is lower triangular throughout)
+            if (io.Lglob) { st_coh2(io.Lglob + p0 + 64 * l, mp0, mp1); st_coh2(io.Lglob + p0 + 2 + 64 * l, mp2, mp3); }
         }
     }
+    finish();
     return bad;
 }
 
@@ -1231,7 +1331,8 @@ __device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
             const int s = 4 * sb + q;
             const int p0 = 16 * sb + 4 * q;
             if (s >= n_piv4) return;
-            cd_wait<1>(sh, 0, s - 1, 0, 0);                  // Ms of block s-2; the inverse wave is done with strip buffer s & 1
+            { const int sp = cd_wait<1>(sh, 0, s - 1, 0, 0);                  // Ms of block s-2; the inverse wave is done with strip buffer s & 1
+              if (C == 0 && l == 0) { CD_SPIN_ADD(4, sp); CD_SPIN_ADD(5, 1); } (void)sp; }
             if (s > 1) {
                 const double* Xq = sh.Xs[(q + 2) & 3];       // panel s-2
                 const double* Mq = sh.Ms[q & 1];             // Ms of block s-2
@@ -1240,9 +1341,14 @@ __device__ __forceinline__ void cd_m_wave(CdShared& sh, int n_piv4, int pending)
 #pragma unroll
                 for (int o = 0; o < NT; ++o) {
                     const int idx = C + CD_MW * o;
-                    if (sb <= cd_tr(idx) || (sb == cd_tr(idx) + 1 && q == 0))
+                    if (sb <= cd_tr(idx) || (sb == cd_tr(idx) + 1 && q == 0)) {
+#if !defined(ABL_NO_M_MFMA)
                         acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xq[lr * 64 + 16 * cd_tr(idx) + lc], -Mq[lr * 64 + 16 * cd_tc(idx) + lc],
                                                                       acc[o], 0, 0, 0);          // M -= X (L4^-1 M(p,:))
+#else
+                        acc[o][0] += Xq[lr * 64 + 16 * cd_tr(idx) + lc] * Mq[lr * 64 + 16 * cd_tc(idx) + lc];
+#endif
+                    }
                 }
             }
             // strip of block s (updates <= s-2 applied): rows p0 + lr of a tile in block row b0 = register q
@@ -1846,8 +1952,10 @@ __device__ __forceinline__ void sw_post_add(int32_t* flag)
 // LDS of the persistent sweep: the chain workgroup's staging areas behind CdShared (see cdp_role)
 constexpr int CDP_AOP_DOUBLES = 64 * CD_OPLD;          // A(k,k-1): [m][CD_OPLD]
 constexpr int CDP_TPRE_DOUBLES = 40 * 64;              // tile (k,k): lower 16 x 16 tiles in accumulator layout [(idx, reg)][lane]
+constexpr int CDP_PEND_DOUBLES = 6 * 4 * 64;           // products of the six trailing tiles outside the first tile column (cdp_t_wave)
 constexpr size_t CDP_OFF_AOP = (sizeof(CdShared) + 15) / 16 * 2;     // in doubles
-constexpr size_t SWP_CHAIN_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES) + 16;
+constexpr size_t SWP_CHAIN_LDS_BYTES = sizeof(double) * (CDP_OFF_AOP + CDP_AOP_DOUBLES + CDP_TPRE_DOUBLES + CDP_PEND_DOUBLES) + 16;
+static_assert(SWP_CHAIN_LDS_BYTES <= 160 * 1024, "the chain workgroup's LDS must fit one compute unit");
 constexpr size_t SWP_LDS_BYTES = SWP_CHAIN_LDS_BYTES > sizeof(double) * 2 * TD_LDS_DOUBLES ? SWP_CHAIN_LDS_BYTES : sizeof(double) * 2 * TD_LDS_DOUBLES;   // tile workers: two engines
 static_assert(SWP_LDS_BYTES >= sizeof(CdShared), "trail_stream_kernel: the diagonal workgroup shares the launch's LDS size");
 
@@ -2308,8 +2416,8 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
 //     tile column c is first read at pivot 16 c);
 //   * L^-1(k-1) is written to global memory right after the chain ends and its flag goes out after the X product;
 //   * L itself is not kept: nobody reads it.
-struct CdpNext {                 // what a T wave fetches for the next block
-    const double* a_src;         // A(k+1,k) + lane (row)
+struct CdpNext {                 // the inputs of the next block, as the strips of its row block hand them over
+    const double* a_base;        // A(k+1,k): row 0, column 0 of the block
     const double* tile;          // tile (k+1,k+1)
     long ldA;
     const int32_t* flag;         // hand-over counter of those tiles ...
@@ -2317,73 +2425,101 @@ struct CdpNext {                 // what a T wave fetches for the next block
     double* Aop; double* Tpre;
 };
 
-// chunk Q (0..3) of T wave B's share: columns B + 4 (4 Q + i), i < 4, of A(k+1,k) and 3/3/2/2 (tile, register) pairs of
-// tile (k+1,k+1).  Small chunks: what a T wave does between two pivot steps must stay well below one step of the chain.
+// A(k+1,k) goes from global memory straight into LDS (global_load_lds_dwordx4, sc1: the strips' stores are write-through): no
+// registers, no ds_write -- the register-staged fetch cost the fetching wave 52 live doubles, and spilled.  Aop is the
+// LDS-DMA image of tile_gemm.h: one transfer = k-rows m and m + 2 (64 rows each), segments TD_SEG doubles apart; the X
+// product reads its A fragments (lane = (k mod 4, row)) from it without bank conflicts.
+static_assert(16 * TD_STEP == CDP_AOP_DOUBLES, "A(k,k-1) as a 64-column LDS-DMA image");
+__device__ __forceinline__ int cdp_aop_index(int m, int row) { return (m >> 2) * TD_STEP + (m & 1) * TD_SEG + ((m >> 1) & 1) * 64 + row; }
+
+// transfers 2 part, 2 part + 1 of T wave B's eight of the 32 (part 0..3)
+template <int B>
+__device__ __forceinline__ void cdp_dma_issue(const CdpNext& nx, int part, unsigned lane_off)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sg = 8 * B + 2 * part + i;
+        const long ku = 4 * (sg >> 1) + (sg & 1);             // wave-uniform: k-rows ku (lanes 0..31) and ku + 2 (lanes 32..63)
+        const char* ga = reinterpret_cast<const char*>(nx.a_base + ku * nx.ldA) + lane_off;
+        __builtin_amdgcn_global_load_lds((tg_glb_void*)ga, (tg_lds_void*)(nx.Aop + sg * TD_SEG), 16, 0, 16);
+    }
+}
+
+// The tile (k+1,k+1) lands in the accumulator layout of the T waves, [(tile, register)][lane]: eight-byte elements, mirrored
+// above the diagonal -- through registers.  Chunk Q (0..3) of share B (0..3): 3/3/2/2 (tile, register) pairs.
 constexpr __device__ int cdp_t0(int q) { return q < 2 ? 3 * q : 6 + 2 * (q - 2); }      // first pair of chunk q: 0, 3, 6, 8 (, 10)
 
 template <int B, int Q>
-__device__ __forceinline__ void cdp_issue(const CdpNext& nx, double (&pf)[26])
+__device__ __forceinline__ void cdp_issue(const CdpNext& nx, double (&pf)[10])
 {
     const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;     // (the lane offsets are loop invariant: the compiler keeps them)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pf[4 * Q + i] = ld_coh(nx.a_src + (long)(B + 4 * (4 * Q + i)) * nx.ldA);
 #pragma unroll
     for (int i = cdp_t0(Q); i < cdp_t0(Q + 1); ++i) {
         const int p = B + 4 * i, idx = p >> 2, reg = p & 3;
         const int row = 16 * cd_tr(idx) + lr + 4 * reg, col = 16 * cd_tc(idx) + lc;
-        pf[16 + i] = ld_coh(nx.tile + ((row >= col) ? row + (long)col * nx.ldA : col + (long)row * nx.ldA));   // lower triangle is authoritative
+        pf[i] = ld_coh(nx.tile + ((row >= col) ? row + (long)col * nx.ldA : col + (long)row * nx.ldA));   // lower triangle is authoritative
     }
 }
 
 template <int B, int Q>
-__device__ __forceinline__ void cdp_store(const CdpNext& nx, const double (&pf)[26])
+__device__ __forceinline__ void cdp_store(const CdpNext& nx, const double (&pf)[10])
 {
     const int l = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nx.Aop[(B + 4 * (4 * Q + i)) * CD_OPLD + l] = pf[4 * Q + i];
-#pragma unroll
-    for (int i = cdp_t0(Q); i < cdp_t0(Q + 1); ++i) nx.Tpre[(B + 4 * i) * 64 + l] = pf[16 + i];
+    for (int i = cdp_t0(Q); i < cdp_t0(Q + 1); ++i) nx.Tpre[(B + 4 * i) * 64 + l] = pf[i];
 }
 
 // q is a constant once the pivot-step loop is unrolled: the switches fold
 template <int B>
-__device__ __forceinline__ void cdp_issue_q(int q, const CdpNext& nx, double (&pf)[26])
+__device__ __forceinline__ void cdp_issue_q(int q, const CdpNext& nx, double (&pf)[10])
 {
     switch (q) { case 0: cdp_issue<B, 0>(nx, pf); break; case 1: cdp_issue<B, 1>(nx, pf); break;
                  case 2: cdp_issue<B, 2>(nx, pf); break; default: cdp_issue<B, 3>(nx, pf); break; }
 }
 template <int B>
-__device__ __forceinline__ void cdp_store_q(int q, const CdpNext& nx, const double (&pf)[26])
+__device__ __forceinline__ void cdp_store_q(int q, const CdpNext& nx, const double (&pf)[10])
 {
     switch (q) { case 0: cdp_store<B, 0>(nx, pf); break; case 1: cdp_store<B, 1>(nx, pf); break;
                  case 2: cdp_store<B, 2>(nx, pf); break; default: cdp_store<B, 3>(nx, pf); break; }
 }
 
-// Top of a block: make this wave's share of the block's inputs LDS-resident.  st: 3 = it already is (fetched and stored
-// during the previous chain), 4 = the loads were issued late in the previous chain and are in pf, 7 = the hand-over flag
-// was seen too late to issue anything, anything else: poll and fetch now (kernel start, or a hand-over that came after
-// the chain had ended: the latency is exposed).
+// Top of a block (T wave B): make this wave's share of the block's inputs LDS-resident.  st: 4 = the transfers were issued
+// during the last steps of the previous chain (the tile's values are in pf), anything else: poll and fetch now (kernel
+// start, or a hand-over that came after the look: the latency is exposed).  The caller's barrier follows; the DMA
+// transfers of this wave are waited for here.
 template <int B>
-__device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, double (&pf)[26], int st)
+__device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, double (&pf)[10], int st, unsigned lane_off)
 {
-    if (st == 3) return;
-    if (st != 4) {
-        if (nx.flag && st != 7) {
-            SwDeadline dl;
-            while (ld_flag(nx.flag) < nx.need) {
-                if (dl.expired()) { sh.timeout = 5; break; }
-                __builtin_amdgcn_s_sleep(1);
+    if (st != 3) {
+        if (st != 4) {
+            if (nx.flag) {
+                SwDeadline dl;
+                while (ld_flag(nx.flag) < nx.need) {
+                    if (dl.expired()) { sh.timeout = 5; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
+            cdp_dma_issue<B>(nx, 0, lane_off); cdp_dma_issue<B>(nx, 1, lane_off); cdp_dma_issue<B>(nx, 2, lane_off); cdp_dma_issue<B>(nx, 3, lane_off);
+            cdp_issue<B, 0>(nx, pf); cdp_issue<B, 1>(nx, pf); cdp_issue<B, 2>(nx, pf); cdp_issue<B, 3>(nx, pf);
         }
-        cdp_issue<B, 0>(nx, pf); cdp_issue<B, 1>(nx, pf); cdp_issue<B, 2>(nx, pf); cdp_issue<B, 3>(nx, pf);
+        cdp_store<B, 0>(nx, pf); cdp_store<B, 1>(nx, pf); cdp_store<B, 2>(nx, pf); cdp_store<B, 3>(nx, pf);
     }
-    cdp_store<B, 0>(nx, pf); cdp_store<B, 1>(nx, pf); cdp_store<B, 2>(nx, pf); cdp_store<B, 3>(nx, pf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA transfers of this wave have landed
 }
 
-// T wave B of the persistent chain.  Returns the state of the fetch of the next block's inputs (see cdp_finish).
+// Pend: LDS images (accumulator layout [reg][lane]) of the products X(tr,:) X(tc,:)^T of trailing tiles 2, 4, 7, 5 (slots 0..3),
+// formed by the four waves that are not T waves while the T waves apply the first tile column (cdp_role), ready at barrier
+// (C).  Tiles 8 and 9 (slots >= 4 mark them) are formed by their owners, T waves 0 and 1, a few MFMAs per step (steps 1..6).
+__device__ constexpr int cdp_pend_slot(int idx) { return idx == 2 ? 0 : idx == 4 ? 1 : idx == 7 ? 2 : idx == 5 ? 3 : idx == 8 ? 4 : idx == 9 ? 5 : -1; }
+
+// T wave B of the persistent chain (round 4: see DESIGN.md section 4, "what bounds the pivot chain").  Returns the state of the
+// fetch of the next block's inputs (this wave's share: eight LDS-DMA transfers of A(k+1,k) and ten values of tile (k+1,k+1)):
+// 4 = issued during steps 12..15, the tile's values are in pf and are stored at the top of the next block; 0 = the hand-over
+// had not come by step 9: the next block fetches everything itself (cdp_finish).
 template <int B>
 __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending, const double* Xb, const double* Tpre,
-                                          const CdpNext& nx, bool want_next, double (&pf)[26], unsigned long long* stamp, int exp_mask)
+                                          const double* Pend, const CdpNext& nx, bool want_next, double (&pf)[10], unsigned lane_off,
+                                          unsigned long long* stamp, int blk = 0)
 {
     const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
     constexpr int NT = (10 - B + CD_TW - 1) / CD_TW;
@@ -2397,25 +2533,47 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
     auto pend = [&](auto O, int k0, int k1) {           // acc[O] -= X(tr,:) X(tc,:)^T over columns k0 .. k1-1
         constexpr int o = decltype(O)::value;
         constexpr int tr = cd_tr(B + CD_TW * o), tc = cd_tc(B + CD_TW * o);
-#pragma unroll 8
+#pragma unroll 4
         for (int kk = k0; kk < k1; kk += 4)
             acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lr) * CD_LD + 16 * tr + lc], -Xb[(kk + lr) * CD_LD + 16 * tc + lc], acc[o], 0, 0, 0);
     };
     if (pending) pend(std::integral_constant<int, EO>{}, 0, 64);
-    if (pending && (exp_mask & 2)) {                  // measurement: every tile column at once, as the one-launch-per-step kernel does
-        static_for<0, NT>([&](auto O) { if (decltype(O)::value != EO) pend(O, 0, 64); });
-    }
     // strip of pivot block 0
     if (lc < 4) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) sh.Tst[0][lc * 64 + 16 * cd_tr(B + CD_TW * EO) + lr + 4 * reg] = acc[EO][reg];
     }
-    __syncthreads();                     // (C) strips, flags are visible
-    // Fetch of the next block's inputs, one chunk per pivot step: the hand-over flag is read at step 4; if it is up at
-    // step 8 the loads go out during steps 8..11 and land in LDS during steps 12..15 (st 1 -> 2 -> 3), else the flag is
-    // read again and, if up at step 12, the loads go out during steps 12..15 and are stored at the top of the next
-    // block (st 5 -> 4); else the next block fetches them itself.
-    int st = 0, fv = 4;
+    __syncthreads();                     // (C) strips, flags, the products of tiles 2, 4, 7, 5 are visible
+    // T(k,k) -= X X^T outside the first tile column: the products were formed by the waves that are not T waves (cdp_role) --
+    // a T wave's step is what paces the pivot chain, so nothing but the rank-4 updates and the strips stays here
+    auto take = [&](auto O) {
+        constexpr int o = decltype(O)::value;
+        constexpr int slot = cdp_pend_slot(B + CD_TW * o);
+        if constexpr (slot >= 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[o][reg] -= Pend[(slot * 4 + reg) * 64 + l];
+        }
+    };
+    const bool late_pending = pending && (cdp_pend_slot(B + CD_TW * (NT - 1)) >= 4);      // tile 8 / 9 (T waves 0 / 1): formed here, a few MFMAs per step
+    // The step loop is software-pipelined: the T waves are the slow side of the pivot pipeline (a -DCD_SPINS build: the
+    // panel wave takes three to four looks per step before its strips are there, T wave 0 finds the panel flag up nine
+    // times out of ten; -DCD_TIMELINE: flag poll, operand fetch, MFMA, strip extraction and post are four dependent LDS /
+    // matrix-pipe latencies in a row, ~1000 cycles against ~750 of the panel wave's step).  So the flag and the operands of
+    // step s+1 are requested right behind the post of step s -- the panel wave has usually finished step s by then -- and
+    // land under this step's remaining MFMAs: a step then starts with its operands in registers.  LDS serves a wave's
+    // requests in order: operands read behind a flag that says "posted" are the posted panel.
+    bool have = false;                 // a[], b[] hold the operands of the coming step
+    double a[NT], b[NT];
+    int st = 0, fv = 0;
+#define CDP_T_LOADS(vflag, Xsrc) do {                                                                                       \
+        vflag = __hip_atomic_load(&sh.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                            \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+        _Pragma("unroll") for (int o = 0; o < NT; ++o) {                                                                     \
+            a[o] = (Xsrc)[lr * 64 + 16 * cd_tr(B + CD_TW * o) + lc];                                                         \
+            b[o] = (Xsrc)[lr * 64 + 16 * cd_tc(B + CD_TW * o) + lc];                                                         \
+        }                                                                                                                  \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+    } while (0)
 #pragma unroll 1
     for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
@@ -2423,19 +2581,43 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             const int s = 4 * sb + q;
             const int p0 = 16 * sb + 4 * q;
             if (s >= n_piv4) return st;
+            CD_STAMP(ts0);
+            if (B == 0 && !CD_TL_M_ON) CD_TL(1, blk, s, 0);
+            const int bb1 = (p0 + 4) >> 4;           // tile column the strip of block s+1 comes from
             if (s > 0) {
-                cd_wait<1>(sh, s, 0, 0, 0);                  // panel s-1 (which also means the panel wave is done with strip buffer (s+1) & 1)
-                const double* Xp = sh.Xs[(q + 3) & 3];
-                double a[NT], b[NT];
-#pragma unroll
-                for (int o = 0; o < NT; ++o) {
-                    a[o] = Xp[lr * 64 + 16 * cd_tr(B + CD_TW * o) + lc];
-                    b[o] = Xp[lr * 64 + 16 * cd_tc(B + CD_TW * o) + lc];
+                int sp = 0;
+                if (!have) {
+                    // panel s-1 (which also means the panel wave is done with strip buffer (s+1) & 1): flag and operands in one
+                    // batch; a flag that is not up is polled alone, then the operands are read again
+                    const double* Xp = sh.Xs[(q + 3) & 3];
+                    int v;
+                    CDP_T_LOADS(v, Xp);
+                    if (__builtin_amdgcn_readfirstlane(v) < s) {
+                        while (true) {
+                            __builtin_amdgcn_s_sleep(1);
+                            v = __hip_atomic_load(&sh.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            ++sp;
+                            if (__builtin_amdgcn_readfirstlane(v) >= s) break;
+                            if (sp > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                        }
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        CDP_T_LOADS(v, Xp);
+                    }
                 }
+                if (B == 0 && !CD_TL_M_ON) CD_TL(1, blk, s, 1);
+                if (B == 0 && (threadIdx.x & 63) == 0) { CD_SPIN_ADD(2, sp + (have ? 0 : 1)); CD_SPIN_ADD(3, 1); }
+                CD_STAMP(ts1);
+                CD_ACC_T(3, ts0, ts1, 128);
+                if (B == 0 && !CD_TL_M_ON) CD_TL(1, blk, s, 2);
                 // (a tile whose 16 columns have all been eliminated -- tile column < sb -- is never read again: no update)
+                // The chain waits for the strip of block s+1, which comes out of ONE tile of this wave (tile column bb1): that
+                // tile's update goes first and the strip is published behind it; the other tiles' updates -- ~100 cycles of the
+                // matrix pipe each -- follow behind the post, off the chain.
+#if !defined(ABL_NO_T_MFMA)
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
-                    if (cd_tc(B + CD_TW * o) >= sb) acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);   // T -= X X^T
+                    if (cd_tc(B + CD_TW * o) == bb1) acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);   // T -= X X^T
+#endif
             }
             // strip of block s+1 (updates <= s-1 applied)
             if (p0 + 4 < 64) {
@@ -2450,32 +2632,257 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
                 }
             }
             cd_post(sh, 2 + B, s + 1);
+            if (B == 0 && !CD_TL_M_ON) CD_TL(1, blk, s, 3);
+            CD_STAMP(ts2);
+            CD_ACC_T(15, ts0, ts2, 128);
             // ---- behind the published strip: work that is not on the chain
-            if (pending && sb == 0 && !(exp_mask & 2)) {
-                // tile columns >= 1 of T -= X X^T: the first other tile during pivot steps 0 and 1 (needed at step 3 at the
-                // earliest), the second during steps 2 and 3 (needed at step 7)
-                constexpr int L1 = (EO == 0) ? 1 : 0, L2 = 2;
-                if (q < 2) { if (L1 < NT) pend(std::integral_constant<int, (L1 < NT ? L1 : 0)>{}, 32 * q, 32 * q + 32); }
-                else { if (L2 < NT && L2 != EO) pend(std::integral_constant<int, (L2 < NT ? L2 : 0)>{}, 32 * (q - 2), 32 * (q - 2) + 32); }
+            // this step's remaining updates first (they still need a[], b[]) ...
+            if (s > 0) {
+#pragma unroll
+                for (int o = 0; o < NT; ++o)
+                    if (cd_tc(B + CD_TW * o) >= sb && cd_tc(B + CD_TW * o) != bb1) {
+#if !defined(ABL_NO_T_MFMA)
+                        acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);
+#else
+                        acc[o][0] += a[o] * b[o];
+#endif
+                    }
+            }
+            // ... then the request for the next step's flag and operands (panel s, buffer q & 3): it lands under the MFMAs above
+            // and under whatever follows in this step
+            int vnext = -1;
+            const bool more = (s + 1 < n_piv4) && (s + 1 < 16);
+            if (more) { const double* Xn = sh.Xs[q & 3]; CDP_T_LOADS(vnext, Xn); }
+            if (pending && s == 0) {
+                // (step 0 has no rank-4 update: the products the other waves left in LDS are taken here)
+                static_for<0, NT>([&](auto O) { if (cdp_pend_slot(B + CD_TW * decltype(O)::value) >= 0 && cdp_pend_slot(B + CD_TW * decltype(O)::value) < 4) take(O); });
+            }
+            if (late_pending && s >= 1 && s <= 6) {
+                // tile 8 (T wave 0; first read at step 7) / tile 9 (T wave 1; step 11): its 16 MFMAs over steps 1..6 (3,3,3,3,2,2)
+                const int k0 = s <= 4 ? 12 * (s - 1) : 48 + 8 * (s - 5), k1 = s <= 4 ? k0 + 12 : k0 + 8;
+                pend(std::integral_constant<int, NT - 1>{}, k0, k1);
             }
             if (want_next) {
-                if (sb == 1 && q == 0) fv = nx.flag ? ld_flag(nx.flag) : 4;     // consumed four steps later: its latency is hidden
-                if (sb == 2) {
-                    if (q == 0 && fv >= nx.need) { st = 1; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
-                    if (q == 1 && st == 0) fv = ld_flag(nx.flag);            // second look, consumed at step 12
-                    if (st == 1) cdp_issue_q<B>(q, nx, pf);
-                    if (q == 3 && st == 1) st = 2;
-                } else if (sb == 3) {
-                    if (q == 0 && st == 0 && fv >= nx.need) { st = 5; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[7] = wall_clock64(); }
-                    if (q == 1 && st == 0) { fv = ld_flag(nx.flag); st = 6; }     // third look, consumed at the top of the next block
-                    if (st == 2) cdp_store_q<B>(q, nx, pf);
-                    else if (st == 5) cdp_issue_q<B>(q, nx, pf);
-                    if (q == 3) { if (st == 2) { st = 3; if (stamp && (threadIdx.x & 63) == 0 && B == 0) stamp[6] = wall_clock64(); } else if (st == 5) st = 4; }
+                // ONE look at the hand-over counter, at step 9, consumed at step 12: by then the strips of the next row block
+                // have long handed over (their L^-1 arrives 0.3 us after the previous chain), and from step 12 on a T wave
+                // owns at most one live tile -- the fetch (eight LDS-DMA transfers, ten loads) goes out during steps 12..15,
+                // where it costs the chain nothing, and the tile's values are stored at the top of the next block.
+                if (sb == 2 && q == 1) fv = ld_flag(nx.flag);
+                if (sb == 3) {
+                    if (q == 0) {
+                        asm volatile("" ::: "memory");           // (a real branch: a select on fv would put the wait for the load behind its issue)
+                        if (fv >= nx.need) { st = 5; if (stamp && l == 0 && B == 0) stamp[7] = wall_clock64(); }
+                    }
+                    if (st == 5) { cdp_dma_issue<B>(nx, q, lane_off); cdp_issue_q<B>(q, nx, pf); if (q == 3) st = 4; }
                 }
             }
+            have = more && (__builtin_amdgcn_readfirstlane(vnext) >= s + 1);
+            CD_STAMP(ts3);
+            CD_ACC_T(4, ts0, ts3, 128);
+            CD_ACC_T(14, ts0, ts0 + 1, 128);
         }
     }
-    return (st == 6 && fv >= nx.need) ? 7 : st;       // 7: not fetched, but the hand-over has been seen: no polling needed
+#undef CDP_T_LOADS
+    return st;
+}
+
+// M wave C of the persistent chain: the running inverse (as cd_m_wave), software-pipelined like the T waves: with the T
+// waves' step cut to what the chain needs, the M waves' five rank-4 updates per step (~145 cycles of a lone wave's matrix
+// pipe each) behind a flag poll and an operand fetch made THEM the slow side (-DCD_SPINS: no failed poll at all).  The flag of
+// the inverse wave and the operands of step s+1 are requested behind the post of step s; the tiles of the block row the next
+// strip comes from are updated first.
+template <int C>
+__device__ __forceinline__ void cdp_m_wave(CdShared& sh, int n_piv4, int blk = 0)
+{
+    const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
+    constexpr int NT = (10 - C + CD_MW - 1) / CD_MW;
+    d4 acc[NT];
+#pragma unroll
+    for (int o = 0; o < NT; ++o)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int idx = C + CD_MW * o;
+            acc[o][reg] = (16 * cd_tr(idx) + lr + 4 * reg == 16 * cd_tc(idx) + lc) ? 1.0 : 0.0;
+        }
+    __syncthreads();                                      // (C)
+    bool have = false;
+    double a[NT], b[NT];
+#define CDP_M_LOADS(vflag, Xsrc, Msrc) do {                                                                                 \
+        vflag = __hip_atomic_load(&sh.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                            \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+        _Pragma("unroll") for (int o = 0; o < NT; ++o) {                                                                     \
+            a[o] = (Xsrc)[lr * 64 + 16 * cd_tr(C + CD_MW * o) + lc];                                                         \
+            b[o] = (Msrc)[lr * 64 + 16 * cd_tc(C + CD_MW * o) + lc];                                                         \
+        }                                                                                                                  \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+    } while (0)
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;
+            const int p0 = 16 * sb + 4 * q;
+            if (s >= n_piv4) return;
+#if defined(CD_TL_M)
+            if (C == 0) CD_TL(1, blk, s, 0);
+#endif
+            const int b0 = p0 >> 4;                          // block row of the strip of block s
+            // needs: Ms of block s-2 (inverse flag >= s-1), which also says the inverse wave is done with strip buffer s & 1
+            int sp = 0;
+            if (!have) {
+                int v;
+                const double* Xq = sh.Xs[(q + 2) & 3];       // panel s-2
+                const double* Mq = sh.Ms[q & 1];             // Ms of block s-2
+                CDP_M_LOADS(v, Xq, Mq);
+                if (__builtin_amdgcn_readfirstlane(v) < s - 1) {
+                    while (true) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(&sh.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++sp;
+                        if (__builtin_amdgcn_readfirstlane(v) >= s - 1) break;
+                        if (sp > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                    }
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    CDP_M_LOADS(v, Xq, Mq);
+                }
+            }
+            if (C == 0 && l == 0) { CD_SPIN_ADD(4, sp + (have ? 0 : 1)); CD_SPIN_ADD(5, 1); }
+#if defined(CD_TL_M)
+            if (C == 0) CD_TL(1, blk, s, 1);
+#endif
+            // (rows of the inverse above the pivot block are final: a tile whose rows all are -- 16 tr + 15 <= 4 (s-2) + 3 --
+            //  gets no more updates); the tiles of block row b0 first: the strip comes out of them
+            if (s > 1) {
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    const int idx = C + CD_MW * o;
+                    if (cd_tr(idx) == b0 && (sb <= cd_tr(idx) || (sb == cd_tr(idx) + 1 && q == 0)))
+                        acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);          // M -= X (L4^-1 M(p,:))
+                }
+            }
+            // strip of block s (updates <= s-2 applied): rows p0 + lr of a tile in block row b0 = register q
+            double* Mo = sh.Mst[q & 1];
+#pragma unroll
+            for (int o = 0; o < NT; ++o) {
+                const int idx = C + CD_MW * o;
+                if (cd_tr(idx) == b0) Mo[lr * 64 + 16 * cd_tc(idx) + lc] = acc[o][q];
+            }
+            cd_post(sh, 2 + CD_TW + C, s + 1);
+#if defined(CD_TL_M)
+            if (C == 0) CD_TL(1, blk, s, 2);
+#endif
+            // ---- behind the published strip: the other tiles' updates, then the request for the next step
+            if (s > 1) {
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    const int idx = C + CD_MW * o;
+                    if (cd_tr(idx) != b0 && (sb <= cd_tr(idx) || (sb == cd_tr(idx) + 1 && q == 0)))
+                        acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);
+                }
+            }
+            int vnext = -1;
+            const bool more = (s + 1 < n_piv4) && (s + 1 < 16);
+            if (more) { const double* Xn = sh.Xs[(q + 3) & 3]; const double* Mn = sh.Ms[(q + 1) & 1]; CDP_M_LOADS(vnext, Xn, Mn); }
+            have = more && (__builtin_amdgcn_readfirstlane(vnext) >= s);
+#if defined(CD_TL_M)
+            if (C == 0) CD_TL(1, blk, s, 3);
+#endif
+        }
+    }
+#undef CDP_M_LOADS
+}
+
+// Inverse wave of the persistent chain: cd_inverse_wave<true> with its rows of L^-1 going to global memory as they become
+// final (CdInvOut), software-pipelined like the T and M waves: the flags and the operands of block s+1 are requested behind
+// the post of block s (the panel wave and the M waves are usually a step ahead) and land under the global stores.
+__device__ __forceinline__ bool cdp_inverse_wave(CdShared& sh, int n_piv4, const CdInvOut io)
+{
+    const int l = threadIdx.x & 63;
+    bool bad = false;
+    double mp0 = 0.0, mp1 = 0.0, mp2 = 0.0, mp3 = 0.0;     // own column of Ms of the previous block
+    if (n_piv4 < 16) {
+        // a last block of fewer than 64 rows: identity beyond the pivots that exist (column l: rows 4 n_piv4 .. 63)
+        for (int row = 4 * n_piv4; row < 64; row += 2) st_coh2(io.Lglob + row + 64 * l, row == l ? 1.0 : 0.0, row + 1 == l ? 1.0 : 0.0);
+    }
+    auto finish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == 0) __hip_atomic_store(io.flag, io.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // flags this wave needs at block s: panel (lane 0) and both M waves (lanes 2 + CD_TW ..) at s + 1
+    const int li = l & 15;
+    const bool mine = (li == 0) || (li >= 2 + CD_TW && li < 2 + CD_TW + CD_MW);
+    bool have = false;
+    double a0, a1, a2, a3, u[16], l10, l20, l30, l21, l31, l32, q0, q1, q2, q3;
+#define CDP_I_LOADS(vflag, qq, pp) do {                                                                                     \
+        vflag = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                           \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+        { const double* Mc = sh.Mst[(qq) & 1]; const double* Xp = sh.Xs[((qq) + 3) & 3]; const double* Xc = sh.Xs[(qq) & 3];   \
+          const double* R = sh.Rs[(qq) & 1];                                                                               \
+          a0 = Mc[l]; a1 = Mc[64 + l]; a2 = Mc[128 + l]; a3 = Mc[192 + l];                                                 \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+              _Pragma("unroll") for (int k = 0; k < 4; ++k) u[4 * j + k] = Xp[j * 64 + (pp) + k];                            \
+          l10 = Xc[(pp) + 1]; l20 = Xc[(pp) + 2]; l30 = Xc[(pp) + 3];                                                      \
+          l21 = Xc[64 + (pp) + 2]; l31 = Xc[64 + (pp) + 3]; l32 = Xc[128 + (pp) + 3];                                      \
+          q0 = R[0]; q1 = R[1]; q2 = R[2]; q3 = R[3]; }                                                                    \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+    } while (0)
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * sb + q;                     // block
+            const int p0 = 16 * sb + 4 * q;
+            if (s >= n_piv4) { finish(); return bad; }
+            int sp = 0;
+            if (!have) {
+                // panel s (L4, reciprocals); strip of block s (M waves, iteration s): flags and operands in one batch
+                int v;
+                CDP_I_LOADS(v, q, p0);
+                if (!__all(!mine || v >= s + 1)) {
+                    while (true) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++sp;
+                        if (__all(!mine || v >= s + 1)) break;
+                        if (sp > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                    }
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    CDP_I_LOADS(v, q, p0);
+                }
+            }
+            if (l == 0) { CD_SPIN_ADD(6, sp + (have ? 0 : 1)); CD_SPIN_ADD(7, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            bad = bad || !(q0 > 1e-300 && q0 < 1e300 && q1 > 1e-300 && q1 < 1e300 && q2 > 1e-300 && q2 < 1e300 && q3 > 1e-300 && q3 < 1e300);
+            {   // strip column l: M(p0+k, l) -= sum_j X_prev(p0+k, j) Ms_prev(j, l)
+                const double ms[4] = {mp0, mp1, mp2, mp3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0 = fma(-u[4 * j + 0], ms[j], a0); a1 = fma(-u[4 * j + 1], ms[j], a1);
+                    a2 = fma(-u[4 * j + 2], ms[j], a2); a3 = fma(-u[4 * j + 3], ms[j], a3);
+                }
+            }
+            // entries right of the pivot columns come out as exact zeros (M is lower triangular)
+            mp0 = a0 * q0;
+            mp1 = fma(-l10, mp0, a1) * q1;
+            mp2 = fma(-l21, mp1, fma(-l20, mp0, a2)) * q2;
+            mp3 = fma(-l32, mp2, fma(-l31, mp1, fma(-l30, mp0, a3))) * q3;
+            double* Mo = sh.Ms[q & 1];
+            Mo[l] = mp0; Mo[64 + l] = mp1; Mo[128 + l] = mp2; Mo[192 + l] = mp3;
+            // column l of rows p0..p0+3 of L^-1 (final)
+            sh.Mf[l * CD_LD + p0 + 0] = mp0; sh.Mf[l * CD_LD + p0 + 1] = mp1;
+            sh.Mf[l * CD_LD + p0 + 2] = mp2; sh.Mf[l * CD_LD + p0 + 3] = mp3;
+            cd_post(sh, 1, s + 1);
+            // the request for the next block's flags and operands, then this block's rows of L^-1 to global memory
+            int vnext = -1;
+            const bool more = (s + 1 < n_piv4) && (s + 1 < 16);
+            if (more) CDP_I_LOADS(vnext, q + 1, p0 + 4);
+            st_coh2(io.Lglob + p0 + 64 * l, mp0, mp1); st_coh2(io.Lglob + p0 + 2 + 64 * l, mp2, mp3);
+            have = more && __all(!mine || vnext >= s + 2);
+        }
+    }
+#undef CDP_I_LOADS
+    finish();
+    return bad;
 }
 
 // One wave role of the chain workgroup over all diagonal blocks.  ROLE: 0 panel wave, 1 inverse wave, 2..5 T waves,
@@ -2493,9 +2900,13 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
     const int row = t & 63;
     constexpr int g = ROLE;                               // wave index
     constexpr bool is_t = (ROLE >= 2 && ROLE < 2 + CD_TW);
+    constexpr bool is_m = (ROLE >= 2 + CD_TW);
     constexpr int TB = is_t ? ROLE - 2 : 0;
+    constexpr int MC = is_m ? ROLE - 2 - CD_TW : 0;
+    double* Pend = Tpre + CDP_TPRE_DOUBLES;               // the products of the tiles outside the first tile column (cdp_t_wave)
     int fetch_st = 0;                                     // (T waves) state of the fetch of block k's inputs, see cdp_finish
-    double pf[26];
+    double pf[10];
+    const unsigned lane_off = td_lane_offset(ldA);        // per-lane part of an LDS-DMA source address
     bool bad = false;
 #pragma unroll 1
     for (int k = 0; k < nblk; ++k) {
@@ -2504,19 +2915,14 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
         const bool pending = k > 0;
         unsigned long long* stamp = (dbg && k < SWD_K) ? dbg + k * SWD_SLOT : nullptr;
         if (stamp && t == 0) stamp[0] = wall_clock64();
-        if (pending) {
-            // L^-1(k-1), complete in Mf (a full block), to global memory for the strips
-            double* Lout = Linv + (long)(k - 1) * 64 * 64;
-#pragma unroll
-            for (int c = g; c < 64; c += CD_THREADS / 64) st_coh(Lout + row + 64 * c, (row >= c) ? sh.Mf[c * CD_LD + row] : 0.0);
-        }
+        // (L^-1(k-1) is in global memory already and its flag is out: the inverse wave wrote its rows as they became final)
         if constexpr (is_t) {
             CdpNext cur;
-            cur.a_src = A + (long)k * 64 + row + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
+            cur.a_base = A + (long)k * 64 + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
             cur.tile = A + (long)k * 64 + (long)k * 64 * ldA;
             cur.ldA = ldA; cur.Aop = Aop; cur.Tpre = Tpre;
             cur.flag = k <= 1 ? &fl->tiles01 : &fl->row_ready[k]; cur.need = k <= 1 ? n_lower_strips : 4;
-            cdp_finish<TB>(cur, sh, pf, fetch_st);
+            cdp_finish<TB>(cur, sh, pf, fetch_st, lane_off);
         }
         __syncthreads();                                  // inputs of block k are in LDS
         if (stamp && t == 0) stamp[1] = wall_clock64();
@@ -2530,15 +2936,13 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
                 const int tc = (ROLE & 1) ? 1 + o : 3 * o;
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
                 for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[(kk + lr) * CD_OPLD + 16 * tr + lc],
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[cdp_aop_index(kk + lr, 16 * tr + lc)],
                                                                sh.Mf[(kk + lr) * CD_LD + 16 * tc + lc], acc, 0, 0, 0);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) Xb[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
             }
-            wait_stores();                                // this wave's part of L^-1(k-1) has reached memory
         }
         __syncthreads();
-        if (pending && t == 0) __hip_atomic_store(&fl->linv_ready, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (stamp && t == 0) stamp[2] = wall_clock64();
         if (pending && !is_t) {
             // X is the panel block L(k,k-1): published for the strips by the four waves that are idle while the T waves
@@ -2547,6 +2951,20 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             double* Xout = Ypanel + (long)k * 64 + (long)(k - 1) * 64 * ldA;
 #pragma unroll
             for (int c = slot; c < 64; c += 4) st_coh(Xout + row + (long)c * ldA, Xb[c * CD_LD + row]);
+            // ... and each of the four forms ONE product of T(k,k) -= X X^T outside the first tile column -- tiles 2, 4, 7, 5 --
+            // for the T wave that owns the tile (cdp_t_wave takes it from LDS behind barrier (C)): 16 MFMAs beside the 16 of
+            // the T waves' first tile column, instead of 8 per pivot step on the T waves during the first steps of the chain
+            {
+                constexpr int pidx = slot == 0 ? 2 : slot == 1 ? 4 : slot == 2 ? 7 : 5;
+                constexpr int ptr_ = cd_tr(pidx), ptc = cd_tc(pidx);
+                const int l = t & 63, lr = l >> 4, lc = l & 15;
+                d4 pacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+                for (int kk = 0; kk < 64; kk += 4)
+                    pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lr) * CD_LD + 16 * ptr_ + lc], Xb[(kk + lr) * CD_LD + 16 * ptc + lc], pacc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Pend[(slot * 4 + reg) * 64 + l] = pacc[reg];
+            }
             wait_stores();
         }
         if (t < 16) sh.flags[t] = 0;
@@ -2556,40 +2974,27 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             __syncthreads();                                         // (C)
             if (pending && t == 0) __hip_atomic_store(&fl->xrow_ready, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (stamp && t == 0) stamp[3] = wall_clock64();
-            cd_panel_wave<false>(sh, n_piv4);
+            cd_panel_wave<false>(sh, n_piv4, k);
             if (stamp && t == 0) stamp[4] = wall_clock64();
         } else if constexpr (ROLE == 1) {
             __syncthreads();
-            bad = cd_inverse_wave<true>(sh, n_piv4) || bad;
+            bad = cdp_inverse_wave(sh, n_piv4, CdInvOut{Linv + (long)k * 64 * 64, &fl->linv_ready, k + 1}) || bad;
         } else if constexpr (is_t) {
             const bool want_next = (k + 1 < nblk) && !(exp_mask & 1);
             CdpNext nx;
-            nx.a_src = A + (long)(k + 1) * 64 + row + (long)k * 64 * ldA;
+            nx.a_base = A + (long)(k + 1) * 64 + (long)k * 64 * ldA;
             nx.tile = A + (long)(k + 1) * 64 + (long)(k + 1) * 64 * ldA;
             nx.ldA = ldA; nx.Aop = Aop; nx.Tpre = Tpre;
             nx.flag = k + 1 <= 1 ? &fl->tiles01 : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4;
-            fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, nx, want_next, pf, stamp, exp_mask);
+            fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, Pend, nx, want_next, pf, lane_off, stamp, k);
         } else {
-            cd_m_wave<ROLE - 2 - CD_TW>(sh, n_piv4, 0);
+            cdp_m_wave<MC>(sh, n_piv4, k);
         }
         __syncthreads();                                  // the chain of block k has ended: L^-1(k) is complete in Mf
         if (stamp && t == 0) stamp[5] = wall_clock64();
         if (sh.timeout) { if (t == 0) atomicMin(status, sh.timeout == 5 ? -35 : -(36 + 10 * k)); return; }     // hand-over protocol broke (never expected)
     }
     if (bad) atomicMin(status, -6);                       // RSLAM_ERR_NOT_SPD
-    {
-        // L^-1 of the last block: identity beyond the rows that exist
-        const int k = nblk - 1;
-        const int done = 4 * ((min(64, max(0, r_total - 64 * k)) + 3) >> 2);
-        double* Lout = Linv + (long)k * 64 * 64;
-        for (int c = g; c < 64; c += CD_THREADS / 64) {
-            const double mv = (row >= done) ? ((row == c) ? 1.0 : 0.0) : sh.Mf[c * CD_LD + row];
-            st_coh(Lout + row + 64 * c, (row >= c) ? mv : 0.0);
-        }
-        wait_stores();
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(&fl->linv_ready, nblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long ldA, int nblk, int r_total, double* Linv, double* Ypanel,
@@ -2598,16 +3003,23 @@ __device__ __forceinline__ void cd_chain_persistent(double* lds, double* A, long
     CdShared& sh = *reinterpret_cast<CdShared*>(lds);
     if (threadIdx.x == 0) sh.timeout = 0;
     __syncthreads();
+    // Which wave plays which role decides who shares a matrix pipe: waves w and w + 4 run on the same SIMD.  Every rank-4
+    // update is one v_mfma_f64_16x16x4 per tile, ~100 cycles of that SIMD's matrix pipe each; T waves 0 / 1 own three tiles,
+    // T waves 2 / 3 two, the M waves five each.  With the roles in wave order (T0 + M0 on SIMD 2, T1 + M1 on SIMD 3: eight
+    // MFMAs per pivot step there, two on SIMDs 0 and 1) the pivot chain waited ~600 cycles per step for the strips of T
+    // waves 0 and 1 (stamped build: the panel wave's own work is ~800 cycles of a ~1500-cycle step).  The M waves therefore
+    // share the SIMDs of the two VALU-only waves (panel, inverse) and the T waves pair up: five MFMAs per SIMD and step.
+#if !defined(CD_ROLES_REMAPPED)
+#define CDP_ROLE_OF_WAVE(w) (w)
+#else
+#define CDP_ROLE_OF_WAVE(w) ((w) < 4 ? (w) : (w) < 6 ? (w) + 2 : (w) - 2)     // waves 4, 5: M waves (roles 6, 7); waves 6, 7: T waves 2, 3
+#endif
+#define CDP_CASE(w) case w: cdp_role<CDP_ROLE_OF_WAVE(w)>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: cdp_role<0>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    case 1: cdp_role<1>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    case 2: cdp_role<2>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    case 3: cdp_role<3>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    case 4: cdp_role<4>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    case 5: cdp_role<5>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    case 6: cdp_role<6>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
-    default: cdp_role<7>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
+    CDP_CASE(0); CDP_CASE(1); CDP_CASE(2); CDP_CASE(3); CDP_CASE(4); CDP_CASE(5); CDP_CASE(6);
+    default: cdp_role<CDP_ROLE_OF_WAVE(7)>(lds, A, ldA, nblk, r_total, Linv, Ypanel, fl, status, dbg, exp_mask, n_lower_strips); break;
     }
+#undef CDP_CASE
 }
 
 
@@ -3097,7 +3509,10 @@ constexpr size_t CD_LDS_BYTES = cd_max(cd_max(sizeof(CdShared), CD_STAGE_BYTES),
 static_assert(CD_TW == 4 && CD_MW == 2, "the role dispatch of cd_factor_block is written out for 4 T waves and 2 M waves");
 static_assert(offsetof(CdShared, Mf) == sizeof(double) * 64 * CD_LD, "the staged operands start where Mf starts");
 
-#if defined(CD_STAMPS)
+#if defined(CD_TIMELINE)
+int debug_read_cd_log(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_log), sizeof(unsigned long long) * 2 * 8 * 16 * 4) == hipSuccess ? 0 : -1; }
+#endif
+#if defined(CD_STAMPS) || defined(CD_SPINS)
 int debug_read_cd_stamps(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_stamps), 128) != hipSuccess) return -1;

@@ -1645,7 +1645,16 @@ extern "C" int rslam_debug_k10_stamps(rslam_ctx* c, unsigned long long* out, int
     return rslam::debug_k10_stamps(out, enable) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
 }
 
-#if defined(CD_STAMPS)
+#if defined(CD_TIMELINE)
+namespace rslam { int debug_read_cd_log(unsigned long long* out); }
+extern "C" int rslam_debug_cd_log(rslam_ctx* c, unsigned long long* out)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return rslam::debug_read_cd_log(out) == 0 ? RSLAM_OK : RSLAM_ERR_HIP;
+}
+#endif
+#if defined(CD_STAMPS) || defined(CD_SPINS)
 namespace rslam { int debug_read_cd_stamps(unsigned long long* out, int reset); }
 extern "C" int rslam_debug_cd_stamps(rslam_ctx* c, unsigned long long* out, int reset)
 {

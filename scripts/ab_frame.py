@@ -46,4 +46,5 @@ if DEBUG:
     print("   vs product library: sets %s, max|dx| %.2e, max|dP|/max|P| %.2e %s" % ("equal" if same else "DIFFER", dx, dP, "OK" if (same and dx < 1e-9 and dP < 1e-9) else "** MISMATCH **"))
     ref.close()
 print("   eager: factor_hi_us mean %.2f median %.2f  total_us median %.1f" % (np.mean(fh), np.median(fh), np.median(tot)))
+print("   counters", ctx.counters(), "last raw status", ctx.last_raw_status())
 print(os.path.basename(api.LIB_PATH_DEBUG if DEBUG else api.LIB_PATH), "compat", compat, "ms/frame", " ".join("%.4f" % v for v in out), "median %.4f" % np.median(out), "n_li", r["n_li"], "n_hi", r["n_hi"])
