@@ -52,22 +52,31 @@ def _compile(job):
     return " ".join(cmd)
 
 
+def _lib_stale(debug):
+    """the library is missing or older than a source / header (objects do not matter: a copy of the tree that carries the
+    built libraries but not the object directory -- the GPU boxes -- must not recompile)"""
+    lib = LIB_DEBUG if debug else LIB
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
 def build(force=False, verbose=False, debug=None, extra_flags=()):
     """debug: False = the product library, True = the diagnostic variant, None = both.  Returns the product library's path
     (the diagnostic one's when debug is True)."""
-    variants = [False, True] if debug is None else [bool(debug)]
-    os.makedirs(OBJ, exist_ok=True)
-    jobs = [(src, dbg, tuple(extra_flags)) for dbg in variants for src in SOURCES if force or extra_flags or _obj_stale(src, dbg)]
-    if jobs:
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
-            for line in ex.map(_compile, jobs):
-                if verbose:
-                    print(line)
-    for dbg in variants:
-        lib = LIB_DEBUG if dbg else LIB
-        objs = [_obj_path(src, dbg) for src in SOURCES]
-        if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
-            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
+    variants = [v for v in ([False, True] if debug is None else [bool(debug)]) if force or extra_flags or _lib_stale(v)]
+    if variants:
+        os.makedirs(OBJ, exist_ok=True)
+        jobs = [(src, dbg, tuple(extra_flags)) for dbg in variants for src in SOURCES if force or extra_flags or _obj_stale(src, dbg)]
+        if jobs:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+                for line in ex.map(_compile, jobs):
+                    if verbose:
+                        print(line)
+        for dbg in variants:
+            lib = LIB_DEBUG if dbg else LIB
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj_path(src, dbg) for src in SOURCES] + ["-o", lib]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -3568,7 +3568,7 @@ static unsigned long long* sweep_dbg_buffer() { return g_sweep_dbg; }
 static unsigned long long* sweep_dbg_buffer() { return nullptr; }
 #endif
 
-// RSLAM_SWEEP_EXP (diagnostic variant of the library only; the product build always runs with mask 0): bit 0 no in-chain fetch of the next block, bit 1 eager T -= X X^T, bit 2 single-block systems take the
+// RSLAM_SWEEP_EXP (diagnostic variant of the library only; the product build always runs with mask 0): bit 0 no in-chain fetch of the next block, bit 1 (unused since round 4), bit 2 single-block systems take the
 // shared route too, bit 3 no register-only route for systems of <= 4 rows, bit 4 fault injection (the chain
 // workgroup does not run), bit 5 fault injection (the strips never announce their Y blocks: tile workers and the x update
 // run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep), bit 8 the time
