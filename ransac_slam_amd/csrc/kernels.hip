@@ -910,6 +910,11 @@ __device__ unsigned long long g_cd_log[2][8][16][4];
 #else
 #define CD_TL(who, blk, step, slot)
 #endif
+#if !defined(CD_ASK_ADAPTIVE)     // (asking ahead only when the step did not have to wait: measured 1 % slower than always asking)
+#define CD_ASK_IF(cond)
+#else
+#define CD_ASK_IF(cond) && (cond)
+#endif
 #if defined(CD_TL_M)
 #define CD_TL_M_ON 1
 #else
@@ -1005,6 +1010,11 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4, int blk 
     int dbg_looks = 0, dbg_steps = 0;
     struct SpinOut { int& a; int& b; __device__ ~SpinOut() { if ((threadIdx.x & 63) == 0) { CD_SPIN_ADD(0, a); CD_SPIN_ADD(1, b); } } } spin_out{dbg_looks, dbg_steps};
     // flag li must reach s + need_off: T waves s, inverse wave and M waves s - 1, nothing else
+    // (Round 4 also built the pipeline TWO updates deep -- the T waves publish the columns of block j+2 in their step j, this
+    //  wave applies the last two rank-4 updates itself: 32 FMAs, sixteen more broadcast reads.  Correct, and no faster: the panel
+    //  wave stops waiting (0.8 extra looks per step instead of 3.3) but its own step grows, and with ~90 KB of LDS traffic per
+    //  step -- half of it broadcast reads that return 1 KB for 16 bytes of data -- the LDS pipe of the compute unit is what
+    //  every wave's round trips queue behind.  HI launch 140-145 us against 142.)
     const int need_off = ((threadIdx.x & 15) >= 2 && (threadIdx.x & 15) < 2 + CD_TW) ? 0
                        : ((threadIdx.x & 15) == 1 || ((threadIdx.x & 15) >= 2 + CD_TW && (threadIdx.x & 15) < 2 + CD_TW + CD_MW)) ? -1 : -(1 << 30);
 #pragma unroll 1
@@ -1028,7 +1038,7 @@ __device__ __forceinline__ void cd_panel_wave(CdShared& sh, int n_piv4, int blk 
                 const int need = s + need_off;
                 // (these sixteen u values are what lanes p0..p0+3 of THIS wave hold in xp0..xp3; taking them by readlane --
                 //  32 v_readlane_b32 under the latency of the other reads -- measured 1 us per block SLOWER than the broadcast
-                //  LDS reads: the chain is bound by the number of instructions this wave issues)
+                //  LDS reads in round 2 and again, with the rebuilt pipeline, in round 4: 138.4 / 141.4 against 138.3 / 136.3 us)
                 int v;
 #define CD_PANEL_LOADS() do {                                                                                              \
                     v = __hip_atomic_load(&sh.flags[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                  \
@@ -2554,7 +2564,8 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             for (int reg = 0; reg < 4; ++reg) acc[o][reg] -= Pend[(slot * 4 + reg) * 64 + l];
         }
     };
-    const bool late_pending = pending && (cdp_pend_slot(B + CD_TW * (NT - 1)) >= 4);      // tile 8 / 9 (T waves 0 / 1): formed here, a few MFMAs per step
+    const bool late_pending = pending && (cdp_pend_slot(B + CD_TW * (NT - 1)) >= 4);      // tile 8 / 9 (T waves 0 / 1): its product arrives later
+    bool late_left = late_pending; (void)late_left;
     // The step loop is software-pipelined: the T waves are the slow side of the pivot pipeline (a -DCD_SPINS build: the
     // panel wave takes three to four looks per step before its strips are there, T wave 0 finds the panel flag up nine
     // times out of ten; -DCD_TIMELINE: flag poll, operand fetch, MFMA, strip extraction and post are four dependent LDS /
@@ -2584,8 +2595,8 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             CD_STAMP(ts0);
             if (B == 0 && !CD_TL_M_ON) CD_TL(1, blk, s, 0);
             const int bb1 = (p0 + 4) >> 4;           // tile column the strip of block s+1 comes from
+            int sp = 0;                              // polls of this step that found the panel flag not yet up
             if (s > 0) {
-                int sp = 0;
                 if (!have) {
                     // panel s-1 (which also means the panel wave is done with strip buffer (s+1) & 1): flag and operands in one
                     // batch; a flag that is not up is polled alone, then the operands are read again
@@ -2640,7 +2651,7 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             if (s > 0) {
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
-                    if (cd_tc(B + CD_TW * o) >= sb && cd_tc(B + CD_TW * o) != bb1) {
+                    if (cd_tc(B + CD_TW * o) > bb1) {           // (tile columns behind bb1 are never read again: no update)
 #if !defined(ABL_NO_T_MFMA)
                         acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);
 #else
@@ -2652,16 +2663,40 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
             // and under whatever follows in this step
             int vnext = -1;
             const bool more = (s + 1 < n_piv4) && (s + 1 < 16);
-            if (more) { const double* Xn = sh.Xs[q & 3]; CDP_T_LOADS(vnext, Xn); }
+            // (only a wave that did not have to wait in this step asks ahead: one that keeps up with its producer would re-read
+            //  the operands at the next step anyway, and the compute unit's LDS pipe is what every round trip queues behind)
+            const bool ask = more CD_ASK_IF(sp == 0);
+            if (ask) { const double* Xn = sh.Xs[q & 3]; CDP_T_LOADS(vnext, Xn); }
             if (pending && s == 0) {
                 // (step 0 has no rank-4 update: the products the other waves left in LDS are taken here)
                 static_for<0, NT>([&](auto O) { if (cdp_pend_slot(B + CD_TW * decltype(O)::value) >= 0 && cdp_pend_slot(B + CD_TW * decltype(O)::value) < 4) take(O); });
             }
+#if defined(CD_LAZY_ON_T)
             if (late_pending && s >= 1 && s <= 6) {
                 // tile 8 (T wave 0; first read at step 7) / tile 9 (T wave 1; step 11): its 16 MFMAs over steps 1..6 (3,3,3,3,2,2)
                 const int k0 = s <= 4 ? 12 * (s - 1) : 48 + 8 * (s - 5), k1 = s <= 4 ? k0 + 12 : k0 + 8;
                 pend(std::integral_constant<int, NT - 1>{}, k0, k1);
             }
+#else
+            if (late_left && s >= 3) {
+                // tile 8 (T wave 0; first read at step 7) / tile 9 (T wave 1; step 11): its product comes from M wave 0 / 1, which
+                // forms it behind its first two (empty) steps; looked for from step 3 on, waited for at step 6
+                int fvv = __hip_atomic_load(&sh.flags[10 + B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (s >= 6) {
+                    int spins = 0;
+                    while (__builtin_amdgcn_readfirstlane(fvv) == 0) {
+                        if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        fvv = __hip_atomic_load(&sh.flags[10 + B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane(fvv) != 0) {
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    take(std::integral_constant<int, NT - 1>{});
+                    late_left = false;
+                }
+            }
+#endif
             if (want_next) {
                 // ONE look at the hand-over counter, at step 9, consumed at step 12: by then the strips of the next row block
                 // have long handed over (their L^-1 arrives 0.3 us after the previous chain), and from step 12 on a T wave
@@ -2676,7 +2711,7 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
                     if (st == 5) { cdp_dma_issue<B>(nx, q, lane_off); cdp_issue_q<B>(q, nx, pf); if (q == 3) st = 4; }
                 }
             }
-            have = more && (__builtin_amdgcn_readfirstlane(vnext) >= s + 1);
+            have = ask && (__builtin_amdgcn_readfirstlane(vnext) >= s + 1);
             CD_STAMP(ts3);
             CD_ACC_T(4, ts0, ts3, 128);
             CD_ACC_T(14, ts0, ts0 + 1, 128);
@@ -2692,7 +2727,7 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
 // the inverse wave and the operands of step s+1 are requested behind the post of step s; the tiles of the block row the next
 // strip comes from are updated first.
 template <int C>
-__device__ __forceinline__ void cdp_m_wave(CdShared& sh, int n_piv4, int blk = 0)
+__device__ __forceinline__ void cdp_m_wave(CdShared& sh, int n_piv4, bool pending, const double* Xb, double* Pend, int blk = 0)
 {
     const int l = threadIdx.x & 63, lr = l >> 4, lc = l & 15;
     constexpr int NT = (10 - C + CD_MW - 1) / CD_MW;
@@ -2780,10 +2815,24 @@ __device__ __forceinline__ void cdp_m_wave(CdShared& sh, int n_piv4, int blk = 0
                         acc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o], -b[o], acc[o], 0, 0, 0);
                 }
             }
+#if !defined(CD_LAZY_ON_T)
+            if (pending && sb == 0 && q == 1) {
+                // The product of trailing tile 8 + C = (3, 2 + C) for T wave C, X(48.., :) X(16 (2 + C).., :)^T over all 64 columns:
+                // this wave's first two steps carry no update of the inverse, and its later steps have slack the T waves lack
+                d4 pacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int kk = 0; kk < 64; kk += 4)
+                    pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lr) * CD_LD + 48 + lc], Xb[(kk + lr) * CD_LD + 16 * (2 + C) + lc], pacc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Pend[((4 + C) * 4 + reg) * 64 + l] = pacc[reg];
+                cd_post(sh, 10 + C, 1);
+            }
+#endif
             int vnext = -1;
             const bool more = (s + 1 < n_piv4) && (s + 1 < 16);
-            if (more) { const double* Xn = sh.Xs[(q + 3) & 3]; const double* Mn = sh.Ms[(q + 1) & 1]; CDP_M_LOADS(vnext, Xn, Mn); }
-            have = more && (__builtin_amdgcn_readfirstlane(vnext) >= s);
+            const bool ask = more CD_ASK_IF(sp == 0);
+            if (ask) { const double* Xn = sh.Xs[(q + 3) & 3]; const double* Mn = sh.Ms[(q + 1) & 1]; CDP_M_LOADS(vnext, Xn, Mn); }
+            have = ask && (__builtin_amdgcn_readfirstlane(vnext) >= s);
 #if defined(CD_TL_M)
             if (C == 0) CD_TL(1, blk, s, 3);
 #endif
@@ -2875,9 +2924,10 @@ __device__ __forceinline__ bool cdp_inverse_wave(CdShared& sh, int n_piv4, const
             // the request for the next block's flags and operands, then this block's rows of L^-1 to global memory
             int vnext = -1;
             const bool more = (s + 1 < n_piv4) && (s + 1 < 16);
-            if (more) CDP_I_LOADS(vnext, q + 1, p0 + 4);
+            const bool ask = more CD_ASK_IF(sp == 0);
+            if (ask) CDP_I_LOADS(vnext, q + 1, p0 + 4);
             st_coh2(io.Lglob + p0 + 64 * l, mp0, mp1); st_coh2(io.Lglob + p0 + 2 + 64 * l, mp2, mp3);
-            have = more && __all(!mine || vnext >= s + 2);
+            have = ask && __all(!mine || vnext >= s + 2);
         }
     }
 #undef CDP_I_LOADS
@@ -2988,7 +3038,7 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             nx.flag = k + 1 <= 1 ? &fl->tiles01 : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4;
             fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, Pend, nx, want_next, pf, lane_off, stamp, k);
         } else {
-            cdp_m_wave<MC>(sh, n_piv4, k);
+            cdp_m_wave<MC>(sh, n_piv4, pending, Xb, Pend, k);
         }
         __syncthreads();                                  // the chain of block k has ended: L^-1(k) is complete in Mf
         if (stamp && t == 0) stamp[5] = wall_clock64();
