@@ -69,6 +69,15 @@ void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int
                 the angle table of ScoreTables::sc */, const DeferArgs* defer = nullptr /* P is P_li: possibly deferred */,
                 const GateList* gl = nullptr /* with defer: list / count come from the rescue flags (no launch_rescue_gate) */);
 
+// K5 (launch_best_mask): what the consensus and the winner's inlier list read and write
+struct SelectArgs {
+    const int32_t* pos; int L; int32_t* sel; uint8_t* li; int32_t* list; const int32_t* sup; int H;
+    const int32_t* nhyp_table; int adaptive; int n_hyp_init;
+    // the inlier masks this frame's scoring launch(es) wrote for EVERY hypothesis (row = hypothesis, or its position when
+    // mask_by_pos), `words` 64-bit words per row; nullptr: the winner is scored again
+    const uint64_t* masks; int words; int mask_by_pos;
+};
+
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                   const double* wv, const ScoreTables& tab, const double* z, int m, int words,
                   const int32_t* pos_list /* nullable = identity */, int n_entries,
@@ -88,7 +97,9 @@ void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
-                      int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init);
+                      int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init,
+                      const uint64_t* masks = nullptr /* every hypothesis' inlier mask of this frame, else the winner is scored again */,
+                      int words = 0, int mask_by_pos = 0);
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
                         const double* S, const double* z, const double* h, double chi2,

@@ -588,24 +588,29 @@ __device__ __forceinline__ int block_incl_sum(int v, int* s_w, int* total)
 // all threads of the block; blockDim.x <= SEL_MAX_THREADS and a multiple of 64; result in sel[0..2]
 __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table,
                                  int adaptive, int n_hyp_init, int32_t* __restrict__ sel,
-                                 int* s_max, int* s_cnt, int* s_rec)
+                                 int* s_max, int* s_cnt, int* s_rec, int* s_nh)
 {
     const int t = threadIdx.x, nt = blockDim.x;
     const int chunk = (H + nt - 1) / nt;
     const int lo = min(H, t * chunk), hi = min(H, lo + chunk);
+    // (the kernel is one workgroup's chain of dependent steps: the thread's first support -- its only one up to 1024
+    //  hypotheses -- is loaded once, and the n_hyp table entries of all records at once, not one per step of the replay)
+    const int v_first = lo < hi ? sup[lo] : 0;
     int mx = 0;
-    for (int i = lo; i < hi; ++i) mx = max(mx, sup[i]);
+    for (int i = lo; i < hi; ++i) mx = max(mx, i == lo ? v_first : sup[i]);
     const int before = block_excl_max(mx, s_max);       // max of everything before the chunk (supports >= 0)
     int run = before;
     int cnt = 0;
-    for (int i = lo; i < hi; ++i) { const int v = sup[i]; if (v > run) { run = v; ++cnt; } }
+    for (int i = lo; i < hi; ++i) { const int v = i == lo ? v_first : sup[i]; if (v > run) { run = v; ++cnt; } }
     int total = 0;
     int wpos = block_incl_sum(cnt, s_max, &total) - cnt;
     run = before;
     for (int i = lo; i < hi; ++i) {
-        const int v = sup[i];
+        const int v = i == lo ? v_first : sup[i];
         if (v > run) { run = v; if (wpos < SEL_MAX_RECORDS) { s_rec[wpos] = i; if (wpos < SEL_MAX_THREADS) s_cnt[wpos] = v; } ++wpos; }
     }
+    __syncthreads();
+    if (adaptive && t < min(total, SEL_MAX_THREADS)) s_nh[t] = nhyp_table[s_cnt[t]];
     if (t == 0) s_max[0] = total;
     __syncthreads();
     if (t == 0) {
@@ -618,7 +623,7 @@ __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const i
             if (i >= n_hyp || i >= H) break;           // loop ended before reaching this record
             best = k < SEL_MAX_THREADS ? s_cnt[k] : sup[i]; besti = i; last = i + 1;   // (the record's support sits beside its index)
             if (adaptive) {
-                n_hyp = nhyp_table[best];
+                n_hyp = k < SEL_MAX_THREADS ? s_nh[k] : nhyp_table[best];
                 if (n_hyp == 0 || i > n_hyp) { evaluated = i + 1; done = true; }   // the two breaks, :533,:536
             }
         }
@@ -654,38 +659,48 @@ __device__ __forceinline__ int block_compact(bool flag, int* s_wave, int* runnin
 
 // Winner's inlier set (Tracking.cpp:507-529) -> li[] flags, ordered feature list,
 // k and the number of 64-column blocks of the stacked system.
-__global__ void __launch_bounds__(1024)
-best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
-                 const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
-                 const int32_t* __restrict__ pos, double thr, int L, int32_t* __restrict__ sel,
-                 uint8_t* __restrict__ li, int32_t* __restrict__ list,
-                 const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table, int adaptive,
-                 int n_hyp_init)
+__device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
+                               const double* __restrict__ wv, const ScoreTables& tab, const double* __restrict__ z, int m,
+                               double thr, const SelectArgs& sa, int* s_wave, int* s_running, int* s_max, int* s_cnt, int* s_rec, int* s_nh)
 {
-    __shared__ int s_wave[16];
-    __shared__ int s_running;
-    __shared__ int s_max[SEL_MAX_THREADS];
-    __shared__ int s_cnt[SEL_MAX_THREADS];
-    __shared__ int s_rec[SEL_MAX_RECORDS];
-    select_consensus(sup, H, nhyp_table, adaptive, n_hyp_init, sel, s_max, s_cnt, s_rec);   // K5
-    if (threadIdx.x == 0) s_running = 0;
-    for (int i = threadIdx.x; i < L; i += blockDim.x) li[i] = 0;
+    int32_t* __restrict__ sel = sa.sel;
+    uint8_t* __restrict__ li = sa.li;
+    int32_t* __restrict__ list = sa.list;
+    // what the winner's scoring needs and does not depend on who wins: requested before the consensus
+    const int j0 = threadIdx.x;
+    int feat0 = -1;
+    if (j0 < m) feat0 = tab.feat[j0];
+    select_consensus(sa.sup, sa.H, sa.nhyp_table, sa.adaptive, sa.n_hyp_init, sel, s_max, s_cnt, s_rec, s_nh);   // K5
+    if (threadIdx.x == 0) *s_running = 0;
+    for (int i = threadIdx.x; i < sa.L; i += blockDim.x) li[i] = 0;
     __syncthreads();
     const int best = s_max[1];                          // (= sel[SEL_BEST_HYP], left there by select_consensus)
-    if (best >= 0) {
+    if (best >= 0 && sa.masks) {
+        // the scoring launch of this frame kept every hypothesis' inlier mask (same arithmetic, same inputs): one word per wave
+        const uint64_t* mrow = sa.masks + (long)(sa.mask_by_pos ? sa.pos[best] : best) * sa.words;
+        for (int base = 0; base < m; base += blockDim.x) {
+            const int j = base + threadIdx.x;
+            const int word = j >> 6;
+            uint64_t bits = 0;
+            if (word < sa.words) bits = mrow[word];
+            const bool inl = (j < m) && ((bits >> (j & 63)) & 1ull);
+            const int slot = block_compact(inl, s_wave, s_running);
+            if (inl) { const int f = base == 0 ? feat0 : tab.feat[j]; li[f] = 1; list[slot] = f; }
+        }
+    } else if (best >= 0) {
         HypCtx hc;
-        hyp_setup(x, W, NP, wv, pos[best], hc);
+        hyp_setup(x, W, NP, wv, sa.pos[best], hc);
         for (int base = 0; base < m; base += blockDim.x) {
             const int j = base + threadIdx.x;
             const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);
-            const int slot = block_compact(inl, s_wave, &s_running);
+            const int slot = block_compact(inl, s_wave, s_running);
             if (inl) { li[tab.feat[j]] = 1; list[slot] = tab.feat[j]; }
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int nblk = (2 * s_running + 63) / 64;
-        sel[SEL_K_LI] = s_running;
+        const int nblk = (2 * *s_running + 63) / 64;
+        sel[SEL_K_LI] = *s_running;
         sel[SEL_NBLK_LI] = nblk;
         sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
         sel[SEL_LI_DEFER] = 0;                       // (an update stage that is re-run starts without a deferred covariance)
@@ -693,15 +708,30 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
     }
 }
 
+__global__ void __launch_bounds__(1024)
+best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
+                 const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
+                 double thr, SelectArgs sa)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_running;
+    __shared__ int s_max[SEL_MAX_THREADS];
+    __shared__ int s_cnt[SEL_MAX_THREADS];
+    __shared__ int s_rec[SEL_MAX_RECORDS];
+    __shared__ int s_nh[SEL_MAX_THREADS];
+    best_mask_body(cam, x, W, NP, wv, tab, z, m, thr, sa, s_wave, &s_running, s_max, s_cnt, s_rec, s_nh);
+}
+
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
-                      int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init)
+                      int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init,
+                      const uint64_t* masks, int words, int mask_by_pos)
 {
     int bs = score_block_size(m);
     if (bs < 256) bs = 256;          // the consensus scan wants a few waves even for tiny maps
-    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, pos, threshold, L, sel, li, list,
-                                                  sup, H, nhyp_table, adaptive, n_hyp_init);
+    const SelectArgs sa{pos, L, sel, li, list, sup, H, nhyp_table, adaptive, n_hyp_init, masks, words, mask_by_pos};
+    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, threshold, sa);
 }
 
 // ---------------------------------------------------------------------------
@@ -1878,6 +1908,9 @@ __device__ __forceinline__ void sw_stamp(unsigned long long* dbg, int who, int k
     if (dbg && (int)threadIdx.x == tid && k < SWD_K) dbg[(who * SWD_K + k) * SWD_SLOT + slot] = wall_clock64();
 }
 
+#ifndef SW_STAMP_STRIP
+#define SW_STAMP_STRIP 8             // the S strip whose steps scripts/sweep_stamps.py shows (first strip of row block 2)
+#endif
 constexpr int SW_MAX_BLOCKS = 32;
 struct SweepFlags {
     int32_t linv_ready;                 // diagonal blocks whose L^-1 is published
@@ -2066,7 +2099,7 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     constexpr int NH = (NJ + 1) / 2;                        // column blocks per group
     const int b = strip >> 2;                               // 64-row block of the strip
     int who = -1;
-    if (dbg) who = (strip == 8) ? 1 : (strip == 4 * (nblk - 1)) ? 2 : (strip == 4 * rp_blocks) ? 3 : (strip == (int)(ldA / 16) - 4) ? 4 : -1;
+    if (dbg) who = (strip == SW_STAMP_STRIP) ? 1 : (strip == 4 * (nblk - 1)) ? 2 : (strip == 4 * rp_blocks) ? 3 : (strip == (int)(ldA / 16) - 4) ? 4 : -1;
     if (who < 0) dbg = nullptr;
     const bool is_s = b < rp_blocks;
     // padding rows of S; row blocks 0 and 1 are the chain's first two diagonal blocks, assembled by the lower strips together
@@ -2137,6 +2170,87 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
 #pragma unroll
             for (int k = 0; k < 13; ++k) Hf[k] = 0.0;
         }
+#if !defined(SW_GATHER_S)
+        if (is_s) {
+            // S rows (round 4): the entries S(a,c) = [a == c] + H_a (P H^T)_c need, of column c of P H^T, the seven pose rows and
+            // the six (three) rows of feature a -- thirteen scattered 8-byte loads per entry and lane when gathered directly:
+            // 312 per lane for a strip of the last row block, whose assembly then took 29 us and held back panel 0 of EVERY
+            // strip (the step-0 update waits for all S strips: the hand-over of row block 3 reached the chain workgroup 3 us
+            // after it needed it).  Now the four waves of a group stage, per column block, the 55 rows of P H^T this strip's
+            // eight features can ask for (thread = (column, two features + two pose rows): <= 14 loads) in LDS and the dots
+            // read from there.  Same products in the same order: the same bits.
+            constexpr int WLD = 65;                             // (odd: the eight features' rows of a column on different banks)
+            constexpr int WST = 55 * WLD;
+            double* Wst = lds + 4096 + g * (2 * WST);           // two stages per group: block jj+1 is fetched under the dots of block jj
+            // lane l < 55 of every wave fetches row `myrow` of P H^T: pose rows 0..6, then six (three) rows per feature of the
+            // strip -- one load instruction per COLUMN (a column of P H^T is contiguous in rows: ~10 cache lines per instruction;
+            // with a lane per column every load touched 64 lines and the vector L1 of the compute unit, one line per clock,
+            // was what the assembly waited for)
+            int myrow = -1;
+            if (l < 7) myrow = l;
+            else if (l < 55) {
+                const int fi = (l - 7) / 6, i = (l - 7) - 6 * fi, a = 16 * strip + 2 * fi;
+                if (a < r_total) { const int fa = src.list[a >> 1]; if (i < ((src.type[fa] == 0) ? 6 : 3)) myrow = src.off[fa] + i; }
+            }
+            const int sl = 7 + 6 * (ln >> 1);                   // first feature row of this lane's S row in the stage
+            double wr[16];                                      // columns 16 w .. 16 w + 15 of the block, row myrow
+            // LI pass: column c of P H^T is column 2 rank_of[list[c / 2]] + (c & 1) of the matched-feature matrix -- two dependent
+            // loads per column: looked up once, lane i < 16 for column 16 w + i of every block of this group, broadcast by readlane
+            int colv[NH];
+#pragma unroll
+            for (int jj = 0; jj < NH; ++jj) {
+                const int c = 64 * (2 * jj + g) + 16 * w + (l & 15);
+                colv[jj] = (src.Wsrc && 2 * jj + g < ncols && c < r_total) ? 2 * src.rank_of[src.list[c >> 1]] + (c & 1) : 0;
+            }
+            auto fetch = [&](auto JJ) {
+                constexpr int jj = decltype(JJ)::value;
+#if !defined(ABL_NO_ASSEMBLY)
+                if constexpr (jj < NH) {
+                    const int j = 2 * jj + g;
+                    if (j < ncols) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int c = 64 * j + 16 * w + i;          // (wave-uniform)
+                            const double* wc = src.Wsrc ? src.Wsrc + (long)__builtin_amdgcn_readlane(colv[jj], i) * NP : A + RP + (long)c * ldA;
+                            wr[i] = (myrow >= 0 && c < r_total) ? wc[myrow] : 0.0;
+                        }
+                    }
+                }
+#endif
+            };
+            fetch(std::integral_constant<int, 0>{});
+            static_for<0, NH>([&](auto JJ) {
+                constexpr int jj = decltype(JJ)::value;
+                const int j = 2 * jj + g;
+                const bool active = j < ncols;
+                double* Wb = Wst + (jj & 1) * WST;
+                acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
+                if (active && l < 55) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Wb[l * WLD + 16 * w + i] = wr[i];
+                }
+                __syncthreads();                                // stage jj is complete (and stage jj-1 has been consumed by everybody)
+                fetch(std::integral_constant<int, jj + 1>{});   // in flight under the dots below
+                if (active) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int cl = 16 * w + lq + 4 * reg, c = 64 * j + cl;
+                        double v = (row == c) ? 1.0 : 0.0;
+#if !defined(ABL_NO_ASSEMBLY)
+                        if (row < r_total && c < r_total) {
+                            double sacc = 0;
+#pragma unroll
+                            for (int k = 0; k < 13; ++k) if (k < fw) sacc += Hf[k] * Wb[(k < 7 ? k : sl + (k - 7)) * WLD + cl];
+                            v += sacc;
+                        }
+#endif
+                        acc[jj][reg] = v;
+                    }
+                }
+            });
+            __syncthreads();                                    // (the stages are free: the step loop reuses this LDS)
+        } else
+#endif
         static_for<0, NH>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
             acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -2678,23 +2792,21 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
                 pend(std::integral_constant<int, NT - 1>{}, k0, k1);
             }
 #else
-            if (late_left && s >= 3) {
+            if (late_left && s == 5) {
                 // tile 8 (T wave 0; first read at step 7) / tile 9 (T wave 1; step 11): its product comes from M wave 0 / 1, which
-                // forms it behind its first two (empty) steps; looked for from step 3 on, waited for at step 6
+                // forms it behind its first two (empty) steps.  It is taken at ONE fixed step -- where in the sequence of rank-4
+                // updates the product is subtracted decides the last bit of the tile, and a take "as soon as the flag is up"
+                // made the factor, and with it x and P, differ in the last place from run to run (scripts/repro_bits.py)
                 int fvv = __hip_atomic_load(&sh.flags[10 + B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (s >= 6) {
-                    int spins = 0;
-                    while (__builtin_amdgcn_readfirstlane(fvv) == 0) {
-                        if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        fvv = __hip_atomic_load(&sh.flags[10 + B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                int spins = 0;
+                while (__builtin_amdgcn_readfirstlane(fvv) == 0) {
+                    if (++spins > CD_SPIN_LIMIT) { sh.timeout = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    fvv = __hip_atomic_load(&sh.flags[10 + B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (__builtin_amdgcn_readfirstlane(fvv) != 0) {
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                    take(std::integral_constant<int, NT - 1>{});
-                    late_left = false;
-                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                take(std::integral_constant<int, NT - 1>{});
+                late_left = false;
             }
 #endif
             if (want_next) {
@@ -2853,10 +2965,9 @@ __device__ __forceinline__ bool cdp_inverse_wave(CdShared& sh, int n_piv4, const
         // a last block of fewer than 64 rows: identity beyond the pivots that exist (column l: rows 4 n_piv4 .. 63)
         for (int row = 4 * n_piv4; row < 64; row += 2) st_coh2(io.Lglob + row + 64 * l, row == l ? 1.0 : 0.0, row + 1 == l ? 1.0 : 0.0);
     }
-    auto finish = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (l == 0) __hip_atomic_store(io.flag, io.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    // (the flag goes out behind the end-of-chain barrier, by the caller: waiting HERE for the last global stores would hold the
+    //  whole workgroup at that barrier for a store round trip, ~0.5 us per block, while the X product only needs L^-1 in LDS)
+    auto finish = [&]() {};
     // flags this wave needs at block s: panel (lane 0) and both M waves (lanes 2 + CD_TW ..) at s + 1
     const int li = l & 15;
     const bool mine = (li == 0) || (li >= 2 + CD_TW && li < 2 + CD_TW + CD_MW);
@@ -3041,6 +3152,11 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             cdp_m_wave<MC>(sh, n_piv4, pending, Xb, Pend, k);
         }
         __syncthreads();                                  // the chain of block k has ended: L^-1(k) is complete in Mf
+        if constexpr (ROLE == 1) {
+            // the inverse wave's rows of L^-1(k) have reached memory: the strips may fetch them (under the other waves' top of the next block)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((t & 63) == 0) __hip_atomic_store(&fl->linv_ready, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (stamp && t == 0) stamp[5] = wall_clock64();
         if (sh.timeout) { if (t == 0) atomicMin(status, sh.timeout == 5 ? -35 : -(36 + 10 * k)); return; }     // hand-over protocol broke (never expected)
     }

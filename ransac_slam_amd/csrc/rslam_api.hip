@@ -61,6 +61,7 @@ struct rslam_ctx {
     int n = 0, NP = 0, L = 0, m = 0, H = 0, words = 0, RP = 0, ldA = 0;
     int m_id = 0, m_euc = 0;
     bool have_state = false, have_meas = false, predicted = false, pht_done = false, dedup_done = false;
+    int masks_all = 0;          // this frame's scoring kept the inlier mask of every hypothesis (1: d_masks, by hypothesis; 2: d_posmask, by position)
     bool have_post = false;      // (d_x2, d_P) hold a posterior x_k_k / p_k_k
     std::vector<uint8_t> h_type, h_vis;
     std::vector<int32_t> h_off;
@@ -99,6 +100,7 @@ struct rslam_ctx {
     int g1_hb = -1, g1_he = -1;
     const void* g1_sup = nullptr;
     const void* g2_sup = nullptr;
+    int g2_masks = -1;
     const int32_t* last_sup = nullptr;
     int graph_captures = 0;
     int last_raw_status = 0;
@@ -346,7 +348,7 @@ static int upload_state(rslam_ctx* c, const rslam_layout* lay, const double* x_p
     if (rc) return rc;
     rc = upload_xp(c, x_pred, P_pred, c->d_xpred.p, c->d_Ppred.p);
     if (rc) return rc;
-    c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false;
+    c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false; c->masks_all = 0;
     return RSLAM_OK;
 }
 
@@ -431,7 +433,7 @@ static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic,
     }
     HIPCHK(hipStreamSynchronize(s));
     (void)tile_order(c, c->NP);          // never inside a graph capture
-    c->have_meas = true; c->pht_done = false; c->dedup_done = false;
+    c->have_meas = true; c->pht_done = false; c->dedup_done = false; c->masks_all = 0;
     return RSLAM_OK;
 }
 
@@ -458,7 +460,7 @@ static int enqueue_predict(rslam_ctx* c)
                    c->d_h.p, c->d_hash.p, c->d_vis.p, c->d_H13.p, c->d_S.p, 1.0 /* features_info[i].R = I, Map.cpp:310 */,
                    c->d_sel.p);
     mark(c, EV_PREDICT);
-    c->predicted = true; c->pht_done = false; c->dedup_done = false; c->patches_valid = false;
+    c->predicted = true; c->pht_done = false; c->dedup_done = false; c->masks_all = 0; c->patches_valid = false;
     return RSLAM_OK;
 }
 
@@ -481,10 +483,12 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
                              nullptr, c->m, c->cfg.sigma_z, c->d_possup.p, c->d_posmask.p);
                 c->dedup_done = true;
             }
+            c->masks_all = 2;
             launch_map_support(s, c->d_possup.p, c->d_pos.p, hb, he, d_sup);
         } else {
             launch_score(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->words,
                          c->d_pos.p + hb, he - hb, c->cfg.sigma_z, d_sup + hb, c->d_masks.p + (size_t)hb * c->words);
+            c->masks_all = (hb == 0 && he == c->H) ? 1 : 0;
         }
     } else if (he > hb) {
         HIPCHK(hipMemsetAsync(d_sup + hb, 0, sizeof(int32_t) * (he - hb), s));
@@ -587,9 +591,16 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     const bool persistent = sweep_is_persistent(c);
     int blocks_li = 1 << 20, blocks_hi = 1 << 20;          // launch-per-step route: read from the device below
     // K5 consensus (Tracking.cpp:507-537)
+    // (the winner's inlier mask is the one the scoring launch kept, where this context scored every hypothesis of the frame;
+    //  with supports from elsewhere -- other ranks -- the winner is scored again)
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
                      c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
-                     c->cfg.adaptive, c->cfg.n_hyp_init);
+                     c->cfg.adaptive, c->cfg.n_hyp_init,
+#if defined(RSLAM_NO_MASKS)
+                     nullptr, 0, 0);
+#else
+                     c->masks_all == 1 ? c->d_masks.p : c->masks_all == 2 ? c->d_posmask.p : nullptr, c->words, c->masks_all == 2);
+#endif
     mark(c, EV_SELECT);
     // Systems too large for the persistent sweep (more 16-row strips than compute units, e.g. 1000 landmarks) run one launch
     // sequence per block step, and how many steps an update needs is only known on the device.  The host reads that one
@@ -978,7 +989,7 @@ extern "C" int rslam_ekf_prediction(rslam_ctx* c, double delta_t, double std_a, 
     HIPCHK(hipMemcpyAsync(c->d_Ppred.p, c->d_P.p, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
     launch_ekf_prediction(s, c->n, c->NP, c->d_x2.p, c->d_P.p, delta_t, std_a, std_alpha, c->d_xpred.p, c->d_Ppred.p, c->d_FQ.p);
     HIPCHK(hipGetLastError());
-    c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false;
+    c->have_state = true; c->have_meas = false; c->predicted = false; c->pht_done = false; c->dedup_done = false; c->masks_all = 0;
     return RSLAM_OK;
 }
 
@@ -1030,7 +1041,7 @@ int apply_map_edit(rslam_ctx* c, int mode, int cut, int special, int shift, int 
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s));
     c->have_post = true; c->have_state = false; c->have_meas = false; c->predicted = false;
-    c->pht_done = false; c->dedup_done = false; c->last_sup = nullptr;
+    c->pht_done = false; c->dedup_done = false; c->masks_all = 0; c->last_sup = nullptr;
     return RSLAM_OK;
 }
 
@@ -1301,6 +1312,7 @@ extern "C" int rslam_step_frame(rslam_ctx* c, int32_t use_graph)
     const int rc = replay(c, 0, [&]() { return enqueue_frame(c); });
     if (rc) return rc;
     c->predicted = true; c->pht_done = true; c->patches_valid = false;
+    c->masks_all = (c->m > 0 && c->H > 0) ? (c->cfg.dedup ? 2 : 1) : 0;        // (what enqueue_score leaves: the replay ran it)
     mark_update_enqueued(c, c->d_sup.p);
     return RSLAM_OK;
 }
@@ -1322,12 +1334,13 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
         const int rc = replay(c, 1, work);
         if (rc) return rc;
         c->predicted = true; c->pht_done = true; c->patches_valid = false;
+        c->masks_all = (c->m > 0 && hyp_end > hyp_begin) ? (c->cfg.dedup ? 2 : (hyp_begin == 0 && hyp_end == c->H) ? 1 : 0) : 0;
         return RSLAM_OK;
     }
     if (!c->predicted) return RSLAM_ERR_STATE;
     auto work = [&]() { return enqueue_update(c, d_supports); };
     if (!use_graph || c->timing || !sweep_is_persistent(c)) return work();
-    if (c->g2_sup != d_supports) { c->graph_valid[2] = false; c->g2_sup = d_supports; }
+    if (c->g2_sup != d_supports || c->g2_masks != c->masks_all) { c->graph_valid[2] = false; c->g2_sup = d_supports; c->g2_masks = c->masks_all; }
     const int rc = replay(c, 2, work);
     if (rc) return rc;
     mark_update_enqueued(c, d_supports);
