@@ -596,11 +596,7 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
                      c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
                      c->cfg.adaptive, c->cfg.n_hyp_init,
-#if defined(RSLAM_NO_MASKS)
-                     nullptr, 0, 0);
-#else
                      c->masks_all == 1 ? c->d_masks.p : c->masks_all == 2 ? c->d_posmask.p : nullptr, c->words, c->masks_all == 2);
-#endif
     mark(c, EV_SELECT);
     // Systems too large for the persistent sweep (more 16-row strips than compute units, e.g. 1000 landmarks) run one launch
     // sequence per block step, and how many steps an update needs is only known on the device.  The host reads that one
