@@ -2177,8 +2177,8 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
             // 312 per lane for a strip of the last row block, whose assembly then took 29 us and held back panel 0 of EVERY
             // strip (the step-0 update waits for all S strips: the hand-over of row block 3 reached the chain workgroup 3 us
             // after it needed it).  Now the four waves of a group stage, per column block, the 55 rows of P H^T this strip's
-            // eight features can ask for (thread = (column, two features + two pose rows): <= 14 loads) in LDS and the dots
-            // read from there.  Same products in the same order: the same bits.
+            // eight features can ask for (lane = row, sixteen columns per wave and block) in LDS, double-buffered, and the
+            // dots read from there.  Same products in the same order: the same bits.  (-DSW_GATHER_S: the direct gather.)
             constexpr int WLD = 65;                             // (odd: the eight features' rows of a column on different banks)
             constexpr int WST = 55 * WLD;
             double* Wst = lds + 4096 + g * (2 * WST);           // two stages per group: block jj+1 is fetched under the dots of block jj
