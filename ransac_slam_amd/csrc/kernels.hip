@@ -2565,7 +2565,18 @@ __device__ __forceinline__ void cdp_dma_issue(const CdpNext& nx, int part, unsig
         const int sg = 8 * B + 2 * part + i;
         const long ku = 4 * (sg >> 1) + (sg & 1);             // wave-uniform: k-rows ku (lanes 0..31) and ku + 2 (lanes 32..63)
         const char* ga = reinterpret_cast<const char*>(nx.a_base + ku * nx.ldA) + lane_off;
+#if defined(CDP_DMA_BUILTIN)   // measurement: the transfer as the compiler's builtin
         __builtin_amdgcn_global_load_lds((tg_glb_void*)ga, (tg_lds_void*)(nx.Aop + sg * TD_SEG), 16, 0, 16);
+#else
+        // Written out, so that the compiler does not know it is a transfer into LDS: it puts s_waitcnt vmcnt(0) in front of
+        // every LDS read that may alias a transfer it knows of -- i.e. in front of the flag and operand reads of the very next
+        // pivot step, a wait for global memory on a wave of the pivot pipeline, in each of the four steps the fetch is spread
+        // over (the blocks that fetched inside the loop had pivot loops 1.2 us longer than those that did not).  Nothing reads
+        // Aop before the next block's top, and cdp_finish waits for vmcnt(0) itself in front of the barrier there.
+        const unsigned lds_addr = (unsigned)(size_t)(tg_lds_void*)(nx.Aop + sg * TD_SEG);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1"
+                     :: "v"(ga), "s"(lds_addr) : "memory", "m0");
+#endif
     }
 }
 
@@ -2819,8 +2830,24 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
                     if (q == 0) {
                         asm volatile("" ::: "memory");           // (a real branch: a select on fv would put the wait for the load behind its issue)
                         if (fv >= nx.need) { st = 5; if (stamp && l == 0 && B == 0) stamp[7] = wall_clock64(); }
+#if !defined(CDP_ONE_LOOK)
+                        else fv = ld_flag(nx.flag);              // a second look, consumed at the last step
+#endif
                     }
                     if (st == 5) { cdp_dma_issue<B>(nx, q, lane_off); cdp_issue_q<B>(q, nx, pf); if (q == 3) st = 4; }
+#if !defined(CDP_ONE_LOOK)
+                    if (q == 3 && st == 0) {
+                        // the hand-over came between steps 9 and 12 (the strips are a little later since the chain got faster):
+                        // the whole fetch in the last step -- its transfers land under the end barrier and the next block's top
+                        asm volatile("" ::: "memory");
+                        if (fv >= nx.need) {
+                            if (stamp && l == 0 && B == 0) stamp[7] = wall_clock64();
+                            cdp_dma_issue<B>(nx, 0, lane_off); cdp_dma_issue<B>(nx, 1, lane_off); cdp_dma_issue<B>(nx, 2, lane_off); cdp_dma_issue<B>(nx, 3, lane_off);
+                            cdp_issue<B, 0>(nx, pf); cdp_issue<B, 1>(nx, pf); cdp_issue<B, 2>(nx, pf); cdp_issue<B, 3>(nx, pf);
+                            st = 4;
+                        }
+                    }
+#endif
                 }
             }
             have = ask && (__builtin_amdgcn_readfirstlane(vnext) >= s + 1);
