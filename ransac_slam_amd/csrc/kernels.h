@@ -69,6 +69,11 @@ void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int
                 the angle table of ScoreTables::sc */, const DeferArgs* defer = nullptr /* P is P_li: possibly deferred */,
                 const GateList* gl = nullptr /* with defer: list / count come from the rescue flags (no launch_rescue_gate) */);
 
+// The launch-per-step route (systems too large for the persistent sweep) sizes its launch sequence on the host from the
+// frame's own counts.  Besides sel[] the kernel that decides a count writes {count, blocks} and then `seq` into page-locked,
+// host-mapped memory (system-scope stores): the host spins on seq instead of paying a copy and a stream synchronisation.
+struct HostCounts { int32_t* p; int32_t seq; };      // p[0] = count, p[1] = blocks, p[2] = seq (nullptr: sel[] only)
+
 // K5 (launch_best_mask): what the consensus and the winner's inlier list read and write
 struct SelectArgs {
     const int32_t* pos; int L; int32_t* sel; uint8_t* li; int32_t* list; const int32_t* sup; int H;
@@ -76,6 +81,7 @@ struct SelectArgs {
     // the inlier masks this frame's scoring launch(es) wrote for EVERY hypothesis (row = hypothesis, or its position when
     // mask_by_pos), `words` 64-bit words per row; nullptr: the winner is scored again
     const uint64_t* masks; int words; int mask_by_pos;
+    HostCounts host;          // launch-per-step route: the update's counts also go to host-visible memory
 };
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
@@ -99,11 +105,11 @@ void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const doub
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
                       int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init,
                       const uint64_t* masks = nullptr /* every hypothesis' inlier mask of this frame, else the winner is scored again */,
-                      int words = 0, int mask_by_pos = 0);
+                      int words = 0, int mask_by_pos = 0, HostCounts host = HostCounts{nullptr, 0});
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
                         const double* S, const double* z, const double* h, double chi2,
-                        uint8_t* hi, int32_t* list, int32_t* sel);
+                        uint8_t* hi, int32_t* list, int32_t* sel, HostCounts host = HostCounts{nullptr, 0});
 
 struct SystemDims { int n, NP, RP, ldA; };   // stacked matrix A: rows [0,RP) S | [RP,RP+NP) W | RP+NP: nu^T (+63 pad)
 

@@ -659,6 +659,15 @@ __device__ __forceinline__ int block_compact(bool flag, int* s_wave, int* runnin
 
 // Winner's inlier set (Tracking.cpp:507-529) -> li[] flags, ordered feature list,
 // k and the number of 64-column blocks of the stacked system.
+// count / blocks / seq to the host (HostCounts): the sequence number last, behind a system-scope fence
+__device__ __forceinline__ void host_counts_store(const HostCounts& hc, int count, int blocks)
+{
+    if (!hc.p) return;
+    __hip_atomic_store(hc.p + 0, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(hc.p + 1, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(hc.p + 2, hc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
                                const double* __restrict__ wv, const ScoreTables& tab, const double* __restrict__ z, int m,
                                double thr, const SelectArgs& sa, int* s_wave, int* s_running, int* s_max, int* s_cnt, int* s_rec, int* s_nh)
@@ -705,6 +714,7 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
         sel[SEL_XU_FLAG] = 0;                        // Jnorm hand-over of this update stage's rank-update launches (tokens 1, 2)
         sel[SEL_LI_DEFER] = 0;                       // (an update stage that is re-run starts without a deferred covariance)
         sel[SEL_K_HI] = 0; sel[SEL_NBLK_HI] = 0;     // written by the second P H^T (GateList); no such launch without matched features
+        host_counts_store(sa.host, *s_running, nblk);
     }
 }
 
@@ -726,11 +736,11 @@ void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const doub
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
                       int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init,
-                      const uint64_t* masks, int words, int mask_by_pos)
+                      const uint64_t* masks, int words, int mask_by_pos, HostCounts host)
 {
     int bs = score_block_size(m);
     if (bs < 256) bs = 256;          // the consensus scan wants a few waves even for tiny maps
-    const SelectArgs sa{pos, L, sel, li, list, sup, H, nhyp_table, adaptive, n_hyp_init, masks, words, mask_by_pos};
+    const SelectArgs sa{pos, L, sel, li, list, sup, H, nhyp_table, adaptive, n_hyp_init, masks, words, mask_by_pos, host};
     best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, threshold, sa);
 }
 
@@ -742,7 +752,7 @@ __global__ void __launch_bounds__(1024)
 rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restrict__ li,
                    const uint8_t* __restrict__ has_h, const double* __restrict__ S,
                    const double* __restrict__ z, const double* __restrict__ h, double chi2,
-                   uint8_t* __restrict__ hi, int32_t* __restrict__ list, int32_t* __restrict__ sel)
+                   uint8_t* __restrict__ hi, int32_t* __restrict__ list, int32_t* __restrict__ sel, HostCounts host)
 {
     __shared__ int s_wave[16];
     __shared__ int s_running;
@@ -768,17 +778,18 @@ rescue_gate_kernel(int L, const uint8_t* __restrict__ ic, const uint8_t* __restr
         const int nblk = (2 * s_running + 63) / 64;
         sel[SEL_K_HI] = s_running;
         sel[SEL_NBLK_HI] = nblk;
+        host_counts_store(host, s_running, nblk);
     }
 }
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
                         const double* S, const double* z, const double* h, double chi2,
-                        uint8_t* hi, int32_t* list, int32_t* sel)
+                        uint8_t* hi, int32_t* list, int32_t* sel, HostCounts host)
 {
     int bs = ((L + 63) / 64) * 64;
     if (bs < 64) bs = 64;
     if (bs > 1024) bs = 1024;
-    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, hi, list, sel);
+    rescue_gate_kernel<<<dim3(1), dim3(bs), 0, s>>>(L, ic, li, has_h, S, z, h, chi2, hi, list, sel, host);
 }
 
 // ---------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <chrono>
 
 #include "../../include/rslam.h"
 #include "kernels.h"
@@ -57,6 +58,9 @@ struct rslam_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // launch-per-step route: the update counts the host sizes its launch sequences from arrive in page-locked, host-mapped memory
+    // (kernels.h HostCounts): [0..2] LI {count, blocks, seq}, [4..6] HI
+    int32_t* h_counts = nullptr; int32_t* d_counts = nullptr; int32_t count_seq = 0;
     // frame shape
     int n = 0, NP = 0, L = 0, m = 0, H = 0, words = 0, RP = 0, ldA = 0;
     int m_id = 0, m_euc = 0;
@@ -249,6 +253,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     if (c->reg_in.ok) (void)hipHostUnregister(const_cast<void*>(c->reg_in.p));
     if (c->reg_out.ok) (void)hipHostUnregister(const_cast<void*>(c->reg_out.p));
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RSLAM_OK;
@@ -575,6 +580,36 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
     return RSLAM_OK;
 }
 
+// The launch-per-step route's counts, host side (kernels.h HostCounts): page-locked, host-mapped memory, allocated on first use
+static HostCounts host_counts_slot(rslam_ctx* c, int base)
+{
+    if (!c->h_counts) {
+        void* h = nullptr; void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+            memset(h, 0, 64);
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) { c->h_counts = (int32_t*)h; c->d_counts = (int32_t*)d; }
+            else (void)hipHostFree(h);
+        }
+        (void)hipGetLastError();
+    }
+    if (!c->h_counts) return HostCounts{nullptr, 0};
+    return HostCounts{c->d_counts + base, ++c->count_seq};
+}
+// spin until the kernel that decides the count has written `seq` behind it; false: no mapped memory, or nothing within 50 ms
+// (a device busy with somebody else's work): the caller then reads sel[] with a copy and a stream synchronisation
+static bool host_counts_wait(rslam_ctx* c, int base, const HostCounts& hc, int32_t* count, int32_t* blocks)
+{
+    if (!hc.p || !c->h_counts) return false;
+    int32_t* p = c->h_counts + base;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(p + 2, __ATOMIC_ACQUIRE) != hc.seq) {
+        if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return false;
+    }
+    *count = __atomic_load_n(p + 0, __ATOMIC_RELAXED); *blocks = __atomic_load_n(p + 1, __ATOMIC_RELAXED);
+    return true;
+}
+
 static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
 {
     if (!c->predicted || !c->have_meas) return RSLAM_ERR_STATE;
@@ -590,23 +625,28 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     }
     const bool persistent = sweep_is_persistent(c);
     int blocks_li = 1 << 20, blocks_hi = 1 << 20;          // launch-per-step route: read from the device below
+    const HostCounts hc_li = persistent ? HostCounts{nullptr, 0} : host_counts_slot(c, 0);
     // K5 consensus (Tracking.cpp:507-537)
     // (the winner's inlier mask is the one the scoring launch kept, where this context scored every hypothesis of the frame;
     //  with supports from elsewhere -- other ranks -- the winner is scored again)
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
                      c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
                      c->cfg.adaptive, c->cfg.n_hyp_init,
-                     c->masks_all == 1 ? c->d_masks.p : c->masks_all == 2 ? c->d_posmask.p : nullptr, c->words, c->masks_all == 2);
+                     c->masks_all == 1 ? c->d_masks.p : c->masks_all == 2 ? c->d_posmask.p : nullptr, c->words, c->masks_all == 2, hc_li);
     mark(c, EV_SELECT);
     // Systems too large for the persistent sweep (more 16-row strips than compute units, e.g. 1000 landmarks) run one launch
     // sequence per block step, and how many steps an update needs is only known on the device.  The host reads that one
-    // integer here (a ~15 us round trip in a frame of milliseconds) and enqueues exactly that many: no sizing from the
-    // previous frame, no overflow, no re-run, no hipGraph re-capture.  Such frames are therefore not captured into graphs.
+    // integer here and enqueues exactly that many: no sizing from the previous frame, no overflow, no re-run, no hipGraph
+    // re-capture.  Such frames are therefore not captured into graphs.  (The count arrives in host-mapped memory, HostCounts: a
+    // copy + stream synchronisation cost 50 us of idle device per read in the kernel trace, and the HI count is known before the
+    // second P H^T has run -- the host enqueues the HI sweep under it.)
     c->li_defer_host = false;
     if (!persistent) {
         int32_t cnt[SEL_NBLK_LI - SEL_K_LI + 1] = {0};            // sel[SEL_K_LI .. SEL_NBLK_LI]
-        HIPCHK(hipMemcpyAsync(cnt, sel + SEL_K_LI, sizeof(cnt), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (!host_counts_wait(c, 0, hc_li, &cnt[0], &cnt[SEL_NBLK_LI - SEL_K_LI])) {
+            HIPCHK(hipMemcpyAsync(cnt, sel + SEL_K_LI, sizeof(cnt), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
         blocks_li = cnt[SEL_NBLK_LI - SEL_K_LI];
         // a low-innovation update of rank <= 4 (compat mode: Q1 leaves one or two inliers) does not stream P: kernels.h MatArgs
 #if defined(RSLAM_DEBUG)
@@ -640,9 +680,10 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     launch_predict(s, c->cam, c->d_x1.p, c->d_P.p, c->NP, c->L, c->d_type.p, c->d_off.p, c->d_h.p, c->d_hash.p,
                    c->d_h2.p, c->d_hash2.p, nullptr, c->d_H13b.p, c->d_S2.p,
                    c->cfg.compat ? 0.0 : 1.0 /* Q7: no +R at Tracking.cpp:589 */, nullptr, &da, gate_apart ? nullptr : &ga);
+    const HostCounts hc_hi = (!persistent && gate_apart) ? host_counts_slot(c, 4) : HostCounts{nullptr, 0};
     if (gate_apart)
         launch_rescue_gate(s, c->L, c->d_ic.p, c->d_li.p, c->d_hash2.p, c->d_S2.p, c->d_z.p, c->d_h2.p, c->cfg.chi2_gate,
-                           c->d_hi.p, c->d_hilist.p, sel);
+                           c->d_hi.p, c->d_hilist.p, sel, hc_hi);
     mark(c, EV_RESCUE);
     // high-innovation update (ExtendKF.cpp:640-678): P H^T at the new linearisation, written straight into A
     const GateList gl{c->d_hi.p, c->L, c->d_hilist.p, sel};
@@ -651,9 +692,11 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
                    c->d_A.p + c->RP, c->ldA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &da,
                    gate_apart ? nullptr : &gl);
     if (!persistent) {
-        int32_t nb = 0;
-        HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_HI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        int32_t nb = 0, k_hi = 0;
+        if (!host_counts_wait(c, 4, hc_hi, &k_hi, &nb)) {
+            HIPCHK(hipMemcpyAsync(&nb, sel + SEL_NBLK_HI, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
         blocks_hi = nb;
     }
     rc = enqueue_one_update(c, c->d_hilist.p, SEL_K_HI, SEL_NBLK_HI, blocks_hi, nullptr, c->d_H13b.p, c->d_h2.p, c->d_x1.p, c->d_x2.p,
