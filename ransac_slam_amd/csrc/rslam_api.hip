@@ -583,6 +583,9 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
 // The launch-per-step route's counts, host side (kernels.h HostCounts): page-locked, host-mapped memory, allocated on first use
 static HostCounts host_counts_slot(rslam_ctx* c, int base)
 {
+#if defined(RSLAM_DEBUG)
+    if (getenv("RSLAM_NO_HOST_COUNTS")) return HostCounts{nullptr, 0};          // tests: the copy + synchronise path
+#endif
     if (!c->h_counts) {
         void* h = nullptr; void* d = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && h) {

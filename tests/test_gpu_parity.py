@@ -576,6 +576,37 @@ def test_large_system_route_short_hi_sweeps(hip, oracle_lib, chi2):
     g.close()
 
 
+def test_large_system_counts_by_mapped_memory_and_by_copy(hip_dbg):
+    """The launch-per-step route learns the update counts through host-mapped memory the deciding kernels write (HostCounts);
+    without the sequence number within 50 ms it falls back to a copy + stream synchronisation.  Both ways on a 600-landmark
+    frame (the rescue gate is a launch of its own beyond 512 landmarks: both counts come that way), diagnostic library with
+    RSLAM_NO_HOST_COUNTS for the copy: identical posterior."""
+    fr = make_frame(L=600, H=60, seed=13)
+    cfg = default_config(compat=0, adaptive=0)
+    res = []
+    for no_map in (False, True):
+        if no_map:
+            os.environ["RSLAM_NO_HOST_COUNTS"] = "1"
+        try:
+            g = hip_dbg.RslamHip(cfg)
+            _, v0, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+            ic = (fr.ic & v0).astype(np.uint8)
+            g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+            for _ in range(3):
+                g.step_frame(False)
+            g.sync()
+            assert g.debug_update_mode() == 0
+            res.append(g.fetch_results())
+            assert g.counters()["sweep_reruns"] == 0
+            g.close()
+        finally:
+            os.environ.pop("RSLAM_NO_HOST_COUNTS", None)
+    a, b = res
+    assert int(a["li"].sum()) > 20 and int(a["hi"].sum()) > 20
+    assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
+    assert np.array_equal(a["x_new"], b["x_new"]) and np.array_equal(a["P_new"], b["P_new"])
+
+
 @pytest.mark.parametrize("compat", [1, 0])
 def test_c5_against_oracle_fixture(hip, compat):
     """BASELINE config C5 (1000 landmarks, n = 6013, 1000 hypotheses) against the oracle: tests/golden/c5/*.npz hold the
