@@ -118,7 +118,7 @@ void launch_prepare_system(hipStream_t s, const SystemDims& d, const int32_t* li
                            int slot_k, int slot_nblk, const double* H13, const int32_t* off,
                            const uint8_t* type, const double* z, const double* h, double* A,
                            const double* Wsrc, const int32_t* rank_of, int32_t* sweep_flags /* SWEEP_FLAG_INTS, zeroed here; nullable */);
-constexpr int SWEEP_FLAG_INTS = 112 + 256;   // hand-over flags of the persistent factor sweep (kernels.hip SweepFlags)
+constexpr int SWEEP_FLAG_INTS = 112 + 256 + 128;   // hand-over flags of the persistent factor sweep (kernels.hip SweepFlags)
 bool sweep_persistent_eligible(const SystemDims& d);
 // The covariance side of an update done INSIDE the persistent sweep launch (K9, K10, K11 without launches of their own):
 // the compute units the sweep leaves idle run tile workers that keep P - Y Y^T of their lower-triangle tile pairs in MFMA

@@ -809,7 +809,7 @@ prepare_system_kernel(SystemDims d, const int32_t* __restrict__ list, const int3
 {
     extern __shared__ __attribute__((aligned(16))) double s_col[];
     const int c = blockIdx.x;
-    if (sweep_flags && c == 0 && threadIdx.x < SWEEP_FLAG_INTS) sweep_flags[threadIdx.x] = 0;   // hand-over flags of the persistent sweep
+    if (sweep_flags && c == 0) for (int i = threadIdx.x; i < SWEEP_FLAG_INTS; i += blockDim.x) sweep_flags[i] = 0;   // hand-over flags of the persistent sweep
     if (c >= 64 * sel[slot_nblk]) return;
     const int r = 2 * sel[slot_k];
     double* col = A + (long)c * d.ldA;
@@ -1933,7 +1933,10 @@ struct SweepFlags {
     int32_t row_cnt[SW_MAX_BLOCKS];     // [b]: panel rows published by the strips of S row block b, all steps (4 per step)
     int32_t y_flag[256];                // [strip]: column blocks of Y (u^T) this P H^T (nu) strip has published -- one word per
                                         // producer, no atomics: the tile workers poll the strips of their own row blocks
+    int32_t tiles01s[4 * 32];           // tiles01 in four shards on cache lines of their own ([32 s], strip & 3): ~120 strips finish
+                                        // their share within a microsecond of each other, and adds to ONE address serialise
 };
+static_assert(SWEEP_FLAG_INTS <= CD_THREADS, "one thread per flag word clears the other set");
 static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag block size");
 // Every wait on another workgroup is bounded in TIME (100 MHz wall clock): the longest legitimate wait is one diagonal block
 // of the chain (~15 us) -- the budget is ~70 times that, so that a launch whose workgroups are not all resident (another user
@@ -2162,7 +2165,11 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
             }
             st_coh(A + a + (long)c * ldA, sys_S(src, A, ldA, NP, RP, r_total, a, c, Hf, fo, fw));
         }
+#if defined(SW_TILES01_ONE)
         sw_post_add(&fl->tiles01);
+#else
+        sw_post_add(&fl->tiles01s[32 * (strip & 3)]);
+#endif
     }
     // acc[jj][reg] of lane (ln, lq) = strip(ln, 64 (2 jj + g) + 16 w + lq + 4 reg); the strip assembles its rows of the
     // stacked system itself (there is no prepare_system pass in front of this kernel)
@@ -2557,8 +2564,16 @@ struct CdpNext {                 // the inputs of the next block, as the strips 
     long ldA;
     const int32_t* flag;         // hand-over counter of those tiles ...
     int need;                    // ... and the count that says they are all there
+    int shards;                  // the counter is the sum of this many words, 32 ints apart (1, or 4: SweepFlags::tiles01s)
     double* Aop; double* Tpre;
 };
+// the hand-over counter of the next block's inputs (all its shards requested at once; the sum when it is used)
+__device__ __forceinline__ int cdp_count(const CdpNext& nx)
+{
+    int v = ld_flag(nx.flag);
+    if (nx.shards == 4) v += ld_flag(nx.flag + 32) + ld_flag(nx.flag + 64) + ld_flag(nx.flag + 96);
+    return v;
+}
 
 // A(k+1,k) goes from global memory straight into LDS (global_load_lds_dwordx4, sc1: the strips' stores are write-through): no
 // registers, no ds_write -- the register-staged fetch cost the fetching wave 52 live doubles, and spilled.  Aop is the
@@ -2640,7 +2655,7 @@ __device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, doub
         if (st != 4) {
             if (nx.flag) {
                 SwDeadline dl;
-                while (ld_flag(nx.flag) < nx.need) {
+                while (cdp_count(nx) < nx.need) {
                     if (dl.expired()) { sh.timeout = 5; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -2836,13 +2851,13 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
                 // have long handed over (their L^-1 arrives 0.3 us after the previous chain), and from step 12 on a T wave
                 // owns at most one live tile -- the fetch (eight LDS-DMA transfers, ten loads) goes out during steps 12..15,
                 // where it costs the chain nothing, and the tile's values are stored at the top of the next block.
-                if (sb == 2 && q == 1) fv = ld_flag(nx.flag);
+                if (sb == 2 && q == 1) fv = cdp_count(nx);
                 if (sb == 3) {
                     if (q == 0) {
                         asm volatile("" ::: "memory");           // (a real branch: a select on fv would put the wait for the load behind its issue)
                         if (fv >= nx.need) { st = 5; if (stamp && l == 0 && B == 0) stamp[7] = wall_clock64(); }
 #if !defined(CDP_ONE_LOOK)
-                        else fv = ld_flag(nx.flag);              // a second look, consumed at the last step
+                        else fv = cdp_count(nx);                 // a second look, consumed at the last step
 #endif
                     }
                     if (st == 5) { cdp_dma_issue<B>(nx, q, lane_off); cdp_issue_q<B>(q, nx, pf); if (q == 3) st = 4; }
@@ -3120,7 +3135,11 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             cur.a_base = A + (long)k * 64 + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
             cur.tile = A + (long)k * 64 + (long)k * 64 * ldA;
             cur.ldA = ldA; cur.Aop = Aop; cur.Tpre = Tpre;
-            cur.flag = k <= 1 ? &fl->tiles01 : &fl->row_ready[k]; cur.need = k <= 1 ? n_lower_strips : 4;
+#if defined(SW_TILES01_ONE)
+            cur.flag = k <= 1 ? &fl->tiles01 : &fl->row_ready[k]; cur.need = k <= 1 ? n_lower_strips : 4; cur.shards = 1;
+#else
+            cur.flag = k <= 1 ? &fl->tiles01s[0] : &fl->row_ready[k]; cur.need = k <= 1 ? n_lower_strips : 4; cur.shards = k <= 1 ? 4 : 1;
+#endif
             cdp_finish<TB>(cur, sh, pf, fetch_st, lane_off);
         }
         __syncthreads();                                  // inputs of block k are in LDS
@@ -3184,7 +3203,11 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             nx.a_base = A + (long)(k + 1) * 64 + (long)k * 64 * ldA;
             nx.tile = A + (long)(k + 1) * 64 + (long)(k + 1) * 64 * ldA;
             nx.ldA = ldA; nx.Aop = Aop; nx.Tpre = Tpre;
-            nx.flag = k + 1 <= 1 ? &fl->tiles01 : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4;
+#if defined(SW_TILES01_ONE)
+            nx.flag = k + 1 <= 1 ? &fl->tiles01 : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4; nx.shards = 1;
+#else
+            nx.flag = k + 1 <= 1 ? &fl->tiles01s[0] : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4; nx.shards = k + 1 <= 1 ? 4 : 1;
+#endif
             fetch_st = cdp_t_wave<TB>(sh, n_piv4, pending, Xb, Tpre, Pend, nx, want_next, pf, lane_off, stamp, k);
         } else {
             cdp_m_wave<MC>(sh, n_piv4, pending, Xb, Pend, k);
