@@ -70,8 +70,10 @@ typedef struct rslam_config {
                             hipHostRegister on first use and keeps the registration while the same pointer comes back -- the
                             reference reuses ExtendKF's members p_k_km1 / p_k_k frame after frame (ExtendKF.h:154-169) -- so
                             the two 26 MB transfers of a frame run at the PCIe rate.  The caller promises that such a buffer
-                            stays allocated until another one has been passed or the context is destroyed (a buffer freed and
-                            re-allocated at the same address would still look registered); off by default for that reason */
+                            stays allocated until rslam_unpin_host_buffers has been called or the context is destroyed (a
+                            buffer freed and re-allocated at the same address would still look registered); a change of the
+                            state dimension drops every registration by itself (the reference re-allocates both matrices
+                            when Map::map_management resizes the state); off by default for that reason */
 } rslam_config;
 
 /* State-vector layout: x = [r(3) q(4) v(3) w(3) | feature 0 | feature 1 | ...]
@@ -204,6 +206,10 @@ int rslam_get_layout        (rslam_ctx* ctx, int32_t* n, int32_t* L, uint8_t* ty
                              int32_t* offset /* L, may be NULL */);
 
 int rslam_fetch_cov  (rslam_ctx* ctx, double* P /* host, n*n */);
+/* Drop the page-lock registrations of RSLAM_PIN_HOST_COV (synchronises first).  To be called before the caller frees or
+ * re-allocates a covariance buffer it has passed to the drop-in calls WITHOUT changing the state dimension -- the reference's
+ * Map::map_management (Map.cpp:88-103) deletes and adds features, which can bring back the same n at the same address. */
+int rslam_unpin_host_buffers(rslam_ctx* ctx);
 int rslam_fetch_state(rslam_ctx* ctx, double* x /* host, n   */);
 /* Per-stage hipEvent timing of eager (non-graph) frames: off by default. */
 int rslam_enable_timing(rslam_ctx* ctx, int on);

@@ -47,6 +47,7 @@ SYMBOLS = {
     "rslam_get_layout": (C.c_int, [C.c_void_p, _i32p, _i32p, _u8p, _i32p]),
     "rslam_fetch_cov": (C.c_int, [C.c_void_p, _dp]),
     "rslam_fetch_state": (C.c_int, [C.c_void_p, _dp]),
+    "rslam_unpin_host_buffers": (C.c_int, [C.c_void_p]),
     "rslam_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rslam_timings": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
     "rslam_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -123,6 +124,17 @@ def lib(debug=False):
     return _lib
 
 
+_lib_other = {}
+
+
+def lib_at(path):
+    """a diagnostic-variant build at another path (ransac_slam_amd/_dev/*.so); raises if it is missing"""
+    path = os.path.abspath(path)
+    if path not in _lib_other:
+        _lib_other[path] = _load(path, {**SYMBOLS, **DEBUG_SYMBOLS}, False)
+    return _lib_other[path]
+
+
 def _p(a, t=_dp):
     return a.ctypes.data_as(t)
 
@@ -135,11 +147,12 @@ def _chk(rc, where):
 class RslamHip:
     """One context on one GPU (one process per GPU in multi-GPU runs)."""
 
-    def __init__(self, cfg: Config, device=0, debug=False):
-        """debug: the context lives in the diagnostic variant of the library (needed by the debug_* methods)"""
+    def __init__(self, cfg: Config, device=0, debug=False, lib_path=None):
+        """debug: the context lives in the diagnostic variant of the library (needed by the debug_* methods);
+        lib_path: another build of the diagnostic variant (build.py build_dev / build_fenced) loaded beside the others"""
         self.cfg = cfg
-        self.debug = bool(debug)
-        self._L = lib(self.debug)
+        self.debug = bool(debug) or lib_path is not None
+        self._L = lib_at(lib_path) if lib_path is not None else lib(self.debug)
         self._h = C.c_void_p()
         _chk(self._L.rslam_create(C.byref(cfg), device, C.byref(self._h)), "rslam_create")
         self.n = self.L = self.H = 0
@@ -322,6 +335,10 @@ class RslamHip:
         draws = np.ascontiguousarray(draws, dtype=np.float64)
         self.H = len(draws)
         _chk(self._L.rslam_load_measurements(self._h, _p(z), _p(ic, _u8p), _p(draws), len(draws)), "rslam_load_measurements")
+
+    def unpin_host_buffers(self):
+        """drop the RSLAM_PIN_HOST_COV registrations (before the caller re-allocates a covariance buffer of the same size)"""
+        _chk(self._L.rslam_unpin_host_buffers(self._h), "rslam_unpin_host_buffers")
 
     def counters(self):
         a, b = C.c_int32(), C.c_int32()

@@ -62,13 +62,15 @@ def _lib_stale(debug):
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False, debug=None, extra_flags=()):
+def build(force=False, verbose=False, debug=None):
     """debug: False = the product library, True = the diagnostic variant, None = both.  Returns the product library's path
-    (the diagnostic one's when debug is True)."""
-    variants = [v for v in ([False, True] if debug is None else [bool(debug)]) if force or extra_flags or _lib_stale(v)]
+    (the diagnostic one's when debug is True).  Takes no extra compiler flags on purpose: an instrumented or ablated build
+    written over librslam_hip.so would look fresh to the next plain build() (staleness is judged by time stamps) and stay
+    the product library -- experiments go through build_dev (a library of their own under _dev/)."""
+    variants = [v for v in ([False, True] if debug is None else [bool(debug)]) if force or _lib_stale(v)]
     if variants:
         os.makedirs(OBJ, exist_ok=True)
-        jobs = [(src, dbg, tuple(extra_flags)) for dbg in variants for src in SOURCES if force or extra_flags or _obj_stale(src, dbg)]
+        jobs = [(src, dbg, ()) for dbg in variants for src in SOURCES if force or _obj_stale(src, dbg)]
         if jobs:
             with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
                 for line in ex.map(_compile, jobs):
@@ -84,6 +86,37 @@ def build(force=False, verbose=False, debug=None, extra_flags=()):
 
 
 DEV_DIR = os.path.join(HERE, "_dev")
+ASM = os.path.join(OBJ, "rel_kernels.s")
+FENCED = os.path.join(DEV_DIR, "fenced.so")
+FENCED_FLAGS = ["-DCD_HW_FENCES", "-DCDP_DMA_BUILTIN"]
+
+
+def _older_than_sources(path):
+    if not os.path.exists(path):
+        return True
+    t = os.path.getmtime(path)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_asm():
+    """Device assembly of the product build of kernels.hip (same flags), for scripts/check_pivot_waitcnt.py: an invariant
+    of the pivot pipeline that only the instruction stream shows (no compiler-inserted wait for global memory in front of
+    the LDS reads of the pivot steps behind the hand-written LDS-DMA)."""
+    if _older_than_sources(ASM):
+        os.makedirs(OBJ, exist_ok=True)
+        subprocess.check_call([_hipcc()] + FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, "kernels.hip"), "-o", ASM])
+    return ASM
+
+
+def build_fenced():
+    """The conservative twin of the diagnostic library, ransac_slam_amd/_dev/fenced.so: every shape, with the hardware
+    fences of the LDS hand-over protocol (-DCD_HW_FENCES) and the in-chain LDS-DMA as the compiler's builtin
+    (-DCDP_DMA_BUILTIN, i.e. with the waits the compiler derives for it).  tests/test_gpu_invariants.py requires the product
+    library's results to be bit-identical to this one's: the two hand-placed relaxations are then not what the results rest on."""
+    if _older_than_sources(FENCED):
+        build_dev("fenced", FENCED_FLAGS, full=True)
+    return FENCED
+
 
 
 def build_dev(name, extra_flags=(), full=False):

@@ -116,15 +116,20 @@ struct rslam_ctx {
     bool k10_riders_first = false;     // a Jnorm wait of the stand-alone rank update timed out once: riders in front from now on
     int k10_reruns = 0;
     int k10_inject = 0;                // fault injection (diagnostic variant of the library only)
-    void* checked_comm = nullptr;      // rslam_shard_frame: the communicator whose size / rank have been checked
+    void* checked_comm = nullptr;      // rslam_shard_frame: the communicator whose size / rank have been checked, with the (rank, world) it was checked for
+    int32_t checked_rank = -1, checked_world = -1;
     // drop-in API: the caller's covariance buffers (p_k_km1 in, p_k_k out) are page-locked on first use so that the two
     // 26 MB transfers of a frame run at the PCIe rate instead of through the runtime's pageable staging
-    struct HostReg { const void* p = nullptr; size_t bytes = 0; bool ok = false; } reg_in, reg_out;
+    // (ONE table for both directions: a caller that swaps its in / out buffers every frame finds both registered)
+    struct HostReg { const void* p = nullptr; size_t bytes = 0; bool ok = false; unsigned long long used = 0; } reg[4];
+    unsigned long long reg_clock = 0;
+    int reg_n = -1;                    // the state dimension the registrations were made for (a resize re-allocates the caller's matrices)
     int rep_status = 0, rep_front = 0, rep_sticky = 0;   // status words of the frame in flight once read_status has taken them off the device
     bool frame_checked = true;         // read_status has (not) looked at the update stage in flight yet
 };
 
 // bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
+static void unpin_host_buffers(rslam_ctx* c);
 static bool sweep_is_persistent(const rslam_ctx* c)
 {
     if (c->steps_frames_left > 0) return false;      // a hand-over of the persistent sweep timed out recently (see read_status)
@@ -250,8 +255,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_sup_local.release(); c->d_sup_all.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
-    if (c->reg_in.ok) (void)hipHostUnregister(const_cast<void*>(c->reg_in.p));
-    if (c->reg_out.ok) (void)hipHostUnregister(const_cast<void*>(c->reg_out.p));
+    unpin_host_buffers(c);
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -315,14 +319,30 @@ static int set_layout(rslam_ctx* c, const rslam_layout* lay)
 // registration that fails -- the caller has pinned it already, the range is not registrable -- is not an error: the copy
 // then takes the pageable path as before.  Only when the caller asked for it (rslam_config.reserved & RSLAM_PIN_HOST_COV:
 // it promises the buffers' lifetime, include/rslam.h).
-static void pin_host_buffer(rslam_ctx* c, rslam_ctx::HostReg& r, const void* p, size_t bytes)
+static void unpin_host_buffers(rslam_ctx* c)
+{
+    for (auto& r : c->reg) {
+        // (a buffer the caller has freed in the meantime fails to unregister: not an error, and no sticky error is left behind)
+        if (r.ok && hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void)hipGetLastError();
+        r = rslam_ctx::HostReg{};
+    }
+}
+
+static void pin_host_buffer(rslam_ctx* c, const void* p, size_t bytes)
 {
     if (!(c->cfg.reserved & RSLAM_PIN_HOST_COV)) return;
-    if (r.p == p && r.bytes == bytes) return;
-    if (r.ok) (void)hipHostUnregister(const_cast<void*>(r.p));
-    r.p = p; r.bytes = bytes;
-    r.ok = (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess);
-    if (!r.ok) (void)hipGetLastError();               // (leave no sticky error behind)
+    // a change of the state dimension means the caller's matrices were re-allocated (Map::map_management resizes x_k_k /
+    // p_k_k): every registration is stale then, even one whose address and size come back later
+    if (c->reg_n != c->n) { unpin_host_buffers(c); c->reg_n = c->n; }
+    rslam_ctx::HostReg* slot = nullptr;
+    for (auto& r : c->reg) {
+        if (r.p == p && r.bytes == bytes) { r.used = ++c->reg_clock; return; }     // known (registered, or known not to be registrable)
+        if (!slot || r.used < slot->used) slot = &r;                                  // least recently used (an empty one first)
+    }
+    if (slot->ok && hipHostUnregister(const_cast<void*>(slot->p)) != hipSuccess) (void)hipGetLastError();
+    slot->p = p; slot->bytes = bytes; slot->used = ++c->reg_clock;
+    slot->ok = (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess);
+    if (!slot->ok) (void)hipGetLastError();            // (leave no sticky error behind)
 }
 
 // host (x, P) -> padded device buffers
@@ -332,7 +352,7 @@ static int upload_xp(rslam_ctx* c, const double* x, const double* P, double* d_x
     const int n = c->n, NP = c->NP;
     HIPCHK(hipMemsetAsync(d_x, 0, sizeof(double) * NP, s));
     HIPCHK(hipMemcpyAsync(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
-    pin_host_buffer(c, c->reg_in, P, sizeof(double) * (size_t)n * n);
+    pin_host_buffer(c, P, sizeof(double) * (size_t)n * n);
     if (NP != n) {
         // one linear transfer, then the leading dimension n -> NP and the zero padding on the device
         if (c->d_stage.ensure((size_t)n * n) < 0) return RSLAM_ERR_HIP;
@@ -1197,7 +1217,7 @@ extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
     if (!c || !P) return RSLAM_ERR_ARG;
     const int rc = settle_posterior(c);          // RSLAM_ERR_STATE unless a posterior exists
     if (rc) return rc;
-    pin_host_buffer(c, c->reg_out, P, sizeof(double) * (size_t)c->n * c->n);
+    pin_host_buffer(c, P, sizeof(double) * (size_t)c->n * c->n);
     if (c->NP != c->n) {
         if (c->d_stage.ensure((size_t)c->n * c->n) < 0) return RSLAM_ERR_HIP;
         launch_repitch(c->stream, c->d_P.p, c->NP, c->d_stage.p, c->n, c->n, c->n, c->n, c->n);
@@ -1207,6 +1227,15 @@ extern "C" int rslam_fetch_cov(rslam_ctx* c, double* P)
         HIPCHK(hipMemcpyAsync(P, c->d_P.p, sizeof(double) * (size_t)c->n * c->n, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    return RSLAM_OK;
+}
+
+extern "C" int rslam_unpin_host_buffers(rslam_ctx* c)
+{
+    if (!c) return RSLAM_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));      // no transfer from / to a registered buffer is in flight
+    unpin_host_buffers(c);
     return RSLAM_OK;
 }
 
@@ -1439,22 +1468,26 @@ extern "C" int rslam_shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, in
         HIPCHK(hipMemsetAsync(c->d_sup_local.p, 0, sizeof(int32_t) * chunk, c->stream));
         HIPCHK(hipMemsetAsync(c->d_sup_all.p, 0, sizeof(int32_t) * (size_t)chunk * world, c->stream));
     }
+    nccl_allgather_fn allgather = nullptr;
+    if (nccl_comm) {
+        const RcclBinding& rccl = bind_rccl();
+        allgather = rccl.allgather;
+        if (!allgather) return RSLAM_ERR_COMM;
+        if (c->checked_comm != nccl_comm || c->checked_rank != rank || c->checked_world != world) {
+            // a communicator of another size, or this process under another index in it, would leave the all-gather hanging
+            // (or scatter the slices wrongly): checked once per (communicator, rank, world), before anything of the frame is
+            // enqueued -- a refused call leaves the context as it was
+            int cnt = -1, me = -1;
+            if (!rccl.count || !rccl.user_rank || rccl.count(nccl_comm, &cnt) != 0 || rccl.user_rank(nccl_comm, &me) != 0) return RSLAM_ERR_COMM;
+            if (cnt != world || me != rank) return RSLAM_ERR_COMM;
+            c->checked_comm = nccl_comm; c->checked_rank = rank; c->checked_world = world;
+        }
+    }
     // phase 0 indexes the support array by global hypothesis id
     int rc = rslam_step_phase(c, 0, begin, end, c->d_sup_local.p - begin, use_graph);
     if (rc) return rc;
     int32_t* full = c->d_sup_local.p;
     if (nccl_comm) {
-        const RcclBinding& rccl = bind_rccl();
-        nccl_allgather_fn allgather = rccl.allgather;
-        if (!allgather) return RSLAM_ERR_COMM;
-        if (c->checked_comm != nccl_comm) {
-            // a communicator of another size, or this process under another index in it, would leave the all-gather hanging
-            // (or scatter the slices wrongly): checked once per communicator, before its first collective
-            int cnt = -1, me = -1;
-            if (!rccl.count || !rccl.user_rank || rccl.count(nccl_comm, &cnt) != 0 || rccl.user_rank(nccl_comm, &me) != 0) return RSLAM_ERR_COMM;
-            if (cnt != world || me != rank) return RSLAM_ERR_COMM;
-            c->checked_comm = nccl_comm;
-        }
         if (allgather(c->d_sup_local.p, c->d_sup_all.p, (size_t)chunk, NCCL_INT32, nccl_comm, c->stream) != 0) return RSLAM_ERR_COMM;
         full = c->d_sup_all.p;
     }

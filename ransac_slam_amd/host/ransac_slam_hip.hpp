@@ -83,8 +83,9 @@ public:
     // reference's initial n_hyp = 1000, Tracking.cpp:357)
     // pin_covariance: page-lock p_k_km1 / p_k_k for the transfers of the drop-in calls (RSLAM_PIN_HOST_COV, include/rslam.h);
     // the two matrices are members of this object, so they outlive every call -- but a resize (Map::map_management adds or
-    // deletes a feature) re-allocates them: the registration follows the new pointer / size, and a caller that resizes back to
-    // an earlier size must not rely on pinning (a re-allocation at the same address would still look registered)
+    // deletes a feature) re-allocates them: the library drops its registrations whenever the state dimension changes, and
+    // map_management code that re-allocates p_k_k / p_k_km1 at an UNCHANGED dimension (a delete followed by an add) calls
+    // covariance_buffers_reallocated() first (rslam_unpin_host_buffers)
     ExtendKF(CamParam* param, int device = 0, int compat = 1, int n_draws = 1400, bool pin_covariance = false)
         : cam(param), n_draws_(n_draws)
     {
@@ -122,6 +123,12 @@ public:
         prior_resident = true;
     }
     bool prior_resident = false;
+    // to be called before p_k_k / p_k_km1 are freed or re-allocated without a change of dimension (pin_covariance only)
+    void covariance_buffers_reallocated()
+    {
+        const int rc = rslam_unpin_host_buffers(ctx_);
+        if (rc) throw Error(rc, "rslam_unpin_host_buffers");
+    }
 
     // Partial update using low-innovation inliers (ExtendKF.cpp:559-596).  The device
     // already ran both updates inside Tracking::ransac_hypotheses; this publishes nothing

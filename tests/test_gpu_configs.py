@@ -340,4 +340,26 @@ def test_dropin_with_pinned_covariance_buffers(hip):
             assert r1[key] == r0[key]
         assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
         assert np.array_equal(r1["x_new"], r0["x_new"]) and np.array_equal(P_out, r0["P_new"])
+    # a caller that swaps its in / out buffers frame by frame (both are in the one registration table), then drops the
+    # registrations (rslam_unpin_host_buffers: what it must do before re-allocating a buffer of the same size) and goes on
+    # with freshly allocated buffers; then a map of another size (every registration is dropped by itself)
+    ref_P = r0["P_new"].copy(order="F")
+    for k in range(4):
+        if k == 2:
+            g1.unpin_host_buffers()
+            P_in = P_in.copy(order="F"); P_out = np.zeros((fr.n, fr.n), order="F")
+        g1.predict(fr.types, fr.x_pred, P_in)
+        r1 = g1.ransac_update(fr.z, ic, fr.draws, P_out=P_out)
+        assert np.array_equal(P_out, ref_P)
+        keep = P_in.copy(order="F")
+        P_in, P_out = P_out, P_in                         # swapped roles next frame
+        P_in[...] = keep
+    fr2 = make_frame(L=90, H=100, seed=906)
+    P2 = np.asfortranarray(fr2.P_pred, dtype=np.float64).copy(order="F")
+    _, vis2, _ = g0.predict(fr2.types, fr2.x_pred, P2.copy(order="F"))
+    ic2 = (fr2.ic & vis2).astype(np.uint8)
+    r0 = g0.ransac_update(fr2.z, ic2, fr2.draws)
+    g1.predict(fr2.types, fr2.x_pred, P2)
+    r1 = g1.ransac_update(fr2.z, ic2, fr2.draws)
+    assert np.array_equal(r1["x_new"], r0["x_new"]) and np.array_equal(r1["P_new"], r0["P_new"])
     g0.close(); g1.close()

@@ -80,6 +80,43 @@ def test_shard_frame_self_gather():
         c.close()
 
 
+def test_shard_frame_refuses_a_communicator_of_another_shape():
+    """A 1-rank communicator offered as rank 0 (or 1) of a world of 2 must come back as RSLAM_ERR_COMM (-8) before anything
+    is enqueued -- on a fresh context, and again on a context that has already validated the SAME communicator for
+    (rank 0, world 1): the check is keyed on (communicator, rank, world), not on the pointer alone."""
+    from ransac_slam_amd import api as hip
+    fr = make_frame(L=40, H=64, seed=303)
+    cfg = default_config(compat=0, adaptive=1)
+    full = _reference(hip, fr, cfg)
+    rccl = _rccl()
+    fresh = hip.RslamHip(cfg)
+    fresh.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    uid = NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        for rank in (0, 1):
+            with pytest.raises(hip.RslamError) as e:
+                fresh.shard_frame(comm.value, rank, 2, False)
+            assert e.value.code == -8
+        assert fresh.counters()["graph_captures"] == 0      # refused before anything of the frame was captured or enqueued
+        fresh.shard_frame(comm.value, 0, 1, False)          # the right shape passes ...
+        fresh.sync()
+        with pytest.raises(hip.RslamError) as e:            # ... and does not whitewash the wrong one afterwards
+            fresh.shard_frame(comm.value, 0, 2, False)
+        assert e.value.code == -8
+        fresh.shard_frame(comm.value, 0, 1, True)
+        fresh.sync()
+        part = fresh.fetch_results()
+        assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+        fresh.close()
+
+
 @pytest.mark.parametrize("compat", [1, 0])
 def test_cpp_shard_frame_example(oracle_lib, tmp_path, compat):
     """host/shard_frame_example.cpp (C++, owns the ncclComm_t) as rank 0 of 1, against the oracle."""
