@@ -516,7 +516,9 @@ def main():
         k_li, k_hi = res_e["n_li"], res_e["n_hi"]
         mode = ctx.update_mode()
         out["update_mode"] = {0: "launch-per-step sweep + stand-alone rank update", 1: "persistent sweep + stand-alone rank update",
-                              2: "persistent sweep with the x / covariance update inside its launch"}[mode]
+                              2: "persistent sweep with the x / covariance update inside its launch",
+                              3: "large-system route, staged: factor sweep of S on a CU-masked stream beside the group solves and "
+                                 "rank-update passes (updates of fewer than 12 column blocks: launch-per-step sweep + rank update)"}[mode]
         r = 2 * k_hi
         f_rank = float(n) * (n + 1) * r              # lower-triangle tiles only: n(n+1)r (SURVEY 8d F_rank)
         f_sweep = r ** 3 / 3.0 + float(n) * r * r    # SURVEY 8d F_update terms of the factor sweep

@@ -283,7 +283,10 @@ int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 /* How the update stage of the loaded frame shape runs: 0 = launch-per-step factor sweep + stand-alone rank update (systems too
  * large for one persistent launch, or the fallback after a timed-out hand-over), 1 = persistent sweep + stand-alone rank
- * update, 2 = persistent sweep with the x / covariance update inside its launch (ExtendKF.cpp:602-609 in one kernel). */
+ * update, 2 = persistent sweep with the x / covariance update inside its launch (ExtendKF.cpp:602-609 in one kernel),
+ * 3 = as 0, and updates of 12 and more column blocks of this context have taken the staged form of that route: the factor
+ * sweep of the innovation covariance alone on a few compute units (a stream with a CU mask) while the others solve
+ * P H^T L^-T and apply P - Y Y^T group by group of column blocks (ExtendKF.cpp:603 beside :608). */
 int rslam_update_mode(rslam_ctx* ctx);
 /* The raw device-side code of the last bounded wait that ran out (0: none): which hand-over it was (rslam_sync folds all of
  * them into RSLAM_ERR_HIP or recovers by re-running the update stage, see rslam_get_counters). */

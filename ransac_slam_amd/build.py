@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librslam_hip.so")
 LIB_DEBUG = os.path.join(HERE, "librslam_hip_dbg.so")
-SOURCES = ["kernels.hip", "map_kernels.hip", "match_kernels.hip", "rslam_api.hip"]
+SOURCES = ["kernels.hip", "staged_kernels.hip", "map_kernels.hip", "match_kernels.hip", "rslam_api.hip"]
 HEADERS = ["kernels.h", "tile_gemm.h", "camera_model.h", os.path.join("..", "..", "include", "rslam.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

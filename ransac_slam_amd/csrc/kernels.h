@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include <functional>
 #include "camera_model.h"
 
 namespace rslam {
@@ -165,6 +166,7 @@ struct XuArgs {
     // launch is the x update alone -- the riders also keep the four columns of Y aside and group 0 sets *defer_flag -- and the
     // covariance is materialised by the HI pass (MatArgs): one stream over P less (134 us at C5)
     int riders_only; double* Y1out; long ldy1; int32_t* defer_flag;
+    int mirror_known;           // != 0: Pin holds exactly mirrored tile pairs (a later pass of a staged update): 1/2 (P + P^T) = P
 };
 // What the tiles of the stand-alone rank update need to start from a deferred P_li (SEL_LI_DEFER) instead of Pin:
 // M = 1/2 (P_pred + P_pred^T) - Y1 Y1^T, then the Jnorm congruence of the low-innovation update (T_li) on rows / columns 3..6
@@ -177,6 +179,14 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
                         const double* Tq /* nullable: 4 x 4 Jnorm, applied to rows/columns 3..6 (K11) when sel[slot_k] != 0 */,
                         int slot_k, const XuArgs* xu /* nullable */, const MatArgs* mat = nullptr /* HI pass: P_li may be deferred */);
 void make_rank_update_order(int nT, std::vector<int32_t>& order);   // XCD-aware (bi << 16 | bj) per block
+
+// ---- the staged route of large systems (staged_kernels.hip; S stage in kernels.hip) ----
+void launch_s_stage(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk, int steps,
+                    double* A, double* Ystore, double* Linv, int32_t* status_sel, int cus, const std::function<void(int)>& progress);
+void launch_group_inverse(hipStream_t s, int b0, int nb, const double* Lp, long ldl, const double* Linv, double* M, double* Mt, long ldm);
+void launch_staged_T(hipStream_t s, const SystemDims& d, int b0, int nb, double* A, const double* Ystore);
+void launch_staged_Y(hipStream_t s, const SystemDims& d, int b0, int nb, const double* A, double* Ystore, const double* M, long ldm);
+int init_staged_kernel_attributes();
 
 // x_pred[0:13], FQ (338 doubles) and the 13-row/column strips of P_pred; the caller copies
 // x[13:] and P beforehand

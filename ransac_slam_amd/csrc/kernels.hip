@@ -1643,7 +1643,9 @@ __device__ __forceinline__ void step_tile(double* __restrict__ A, long ldA, int 
 {
     if (!row_block_active(i, step, nblk, rp_blocks)) return;
     const bool has_col = (j < nblk) && (i >= j) && !(i == step + 1 && j == step + 1);   // (k+1,k+1) belongs to workgroup 0
-    const bool store_y = (j == step + 1) && (i >= rp_blocks || (store_s_rows && i >= step + 2));
+    // (store_s_rows: also tile (k+1, k), whose product the diagonal workgroup forms for itself and keeps in LDS: the staged
+    //  route's group inverse reads every L(a, c) from the second buffer)
+    const bool store_y = (j == step + 1) && (i >= rp_blocks || (store_s_rows && i >= step + 1));
     if (!has_col && !store_y) return;
     double* bufA = lds;                               // A(i,k), then Y_i
     double* bufB = lds + 2 * TG_OPER_DOUBLES;         // Linv(k)
@@ -3930,6 +3932,42 @@ double* launch_factor_sweep(hipStream_t s, const SystemDims& d,
     return Ystore;
 }
 
+// The S stage of the staged route (staged_kernels.hip): the same block steps in pairs as the large-system branch above, on the
+// r x r innovation covariance ALONE -- the S rows of the stacked system; P H^T and nu^T are not swept, the R stage solves them
+// group by group.  After it: Linv holds the inverse of every diagonal block, the S rows of Ystore every panel block L(a, c),
+// a > c (the narrow pass also stores tile (k+1, k)).  progress(f) is called behind each launch after which the diagonal
+// blocks [0, f) are factored and the panel blocks of the columns [0, f - 1) are stored: what a group that ends at f needs.
+// cus: compute units of the stream's CU mask (sizes the wide passes).
+void launch_s_stage(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk, int steps,
+                    double* A, double* Ystore, double* Linv, int32_t* status_sel, int cus, const std::function<void(int)>& progress)
+{
+    const int rp_blocks = d.RP / 64;
+    if (steps > rp_blocks) steps = rp_blocks;
+    if (steps <= 0) return;
+    const int row_blocks = rp_blocks;                              // S rows only
+    const size_t lds_bytes = sizeof(double) * TG_LDS_DOUBLES;
+    chol_diag_kernel<<<dim3(1), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(A, d.ldA, 0, sel, slot_nblk, slot_k, Linv, status_sel, 0);
+    progress(1);
+    int step = 0;
+    while (step + 1 < steps) {
+        const bool pair = step + 2 < steps;
+        sweep_step_kernel<<<dim3(1 + row_blocks + (pair ? 1 : 0)), dim3(CD_THREADS), CD_LDS_BYTES, s>>>(
+            A, d.ldA, step, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, Ystore, status_sel, pair ? 2 : 1);
+        progress(step + 2);
+        if (!pair) break;
+        panel_kernel<<<dim3(row_blocks), dim3(256), lds_bytes, s>>>(A, d.ldA, step + 1, sel, slot_nblk, Linv, rp_blocks, Ystore);
+        const long nS = steps - (step + 2);
+        const long total = nS * (nS + 1) / 2;
+        long W = (total + 1) / 2;
+        if (W > cus - 1) W = cus - 1;
+        if (W < 1) W = 1;
+        trail_stream2_kernel<<<dim3(1 + (int)W), dim3(CD_THREADS), SWP_LDS_BYTES, s>>>(
+            A, d.ldA, TrailPass{step, step + 2}, sel, slot_nblk, slot_k, rp_blocks, row_blocks, Linv, status_sel, Ystore);
+        progress(step + 3);
+        step += 2;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K9: x_k_k = x + K (z - h) = x + Y u (ExtendKF.cpp:606), then quaternion
 // normalisation and the Jnorm matrix (:613-627; Q6: exponent -3/2 is integer
@@ -4108,7 +4146,8 @@ rank_update_kernel(int nT, const double* Pin, long ldp, const double* __restrict
     // The HI pass reads what the LI pass wrote: mirrored tile pairs, i.e. exactly symmetric off the diagonal tiles, so
     // 1/2 (P + P^T) = P there bit for bit and the mirror tile need not be read (a quarter of this pass's reads).  Not
     // when the LI pass was a pass-through (no inliers: its output is the prior as uploaded).
-    const bool mirror_known = !deferred && (xu.token == 2) && (bi != bj) && (sel[SEL_NBLK_LI] > 0);
+    // (xu.mirror_known: a later pass of a staged update -- the first pass of the same update wrote mirrored pairs)
+    const bool mirror_known = !deferred && (bi != bj) && (xu.mirror_known || ((xu.token == 2) && (sel[SEL_NBLK_LI] > 0)));
     // Both P tiles are requested before the K loop and land under it: the epilogue is left with the stores only.
     double pij[16], pji[16];
 #pragma unroll

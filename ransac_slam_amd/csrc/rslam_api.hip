@@ -126,10 +126,23 @@ struct rslam_ctx {
     int reg_n = -1;                    // the state dimension the registrations were made for (a resize re-allocates the caller's matrices)
     int rep_status = 0, rep_front = 0, rep_sticky = 0;   // status words of the frame in flight once read_status has taken them off the device
     bool frame_checked = true;         // read_status has (not) looked at the update stage in flight yet
+    // Staged route of large systems (staged_kernels.hip): three side streams with disjoint CU masks -- the S stage (pivot chain
+    // of the innovation covariance), the group inverses, the R stage (everything with n rows) -- joined to the context's
+    // stream by events; created on first use, absent (ok == false) when the runtime refuses CU masks
+    struct Staged {
+        bool tried = false, ok = false;
+        hipStream_t sS = nullptr, sI = nullptr, sR = nullptr;
+        int cus_S = 0, cus_I = 0;
+        static constexpr int MAX_GROUPS = 8;
+        hipEvent_t e0 = nullptr, eGrp[MAX_GROUPS] = {}, eInv[MAX_GROUPS] = {}, eR[MAX_GROUPS] = {};
+        DevBuf<double> d_M, d_Mt;      // group inverses L_gg^-1 (RP x RP, the groups' diagonal blocks) and their transposes
+        int updates = 0;               // updates that took the route (rslam_update_mode reports it)
+    } staged;
 };
 
 // bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
 static void unpin_host_buffers(rslam_ctx* c);
+static void staged_release(rslam_ctx* c);
 static bool sweep_is_persistent(const rslam_ctx* c)
 {
     if (c->steps_frames_left > 0) return false;      // a hand-over of the persistent sweep timed out recently (see read_status)
@@ -256,6 +269,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     unpin_host_buffers(c);
+    staged_release(c);
     if (c->ev_ok) for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -541,6 +555,163 @@ static const int32_t* tile_order(rslam_ctx* c, int NP)
     return c->d_tile_order.p;
 }
 
+
+// ------------------------------------------------------------------------
+// Staged route of large systems (see staged_kernels.hip)
+// ------------------------------------------------------------------------
+static void staged_release(rslam_ctx* c)
+{
+    rslam_ctx::Staged& st = c->staged;
+    for (hipStream_t* sp : {&st.sS, &st.sI, &st.sR}) if (*sp) { (void)hipStreamSynchronize(*sp); (void)hipStreamDestroy(*sp); *sp = nullptr; }
+    if (st.e0) { (void)hipEventDestroy(st.e0); st.e0 = nullptr; }
+    for (int g = 0; g < rslam_ctx::Staged::MAX_GROUPS; ++g) {
+        if (st.eGrp[g]) { (void)hipEventDestroy(st.eGrp[g]); st.eGrp[g] = nullptr; }
+        if (st.eInv[g]) { (void)hipEventDestroy(st.eInv[g]); st.eInv[g] = nullptr; }
+        if (st.eR[g]) { (void)hipEventDestroy(st.eR[g]); st.eR[g] = nullptr; }
+    }
+    st.d_M.release(); st.d_Mt.release();
+    st.ok = false;
+}
+
+static int staged_env_int(const char* name, int dflt)
+{
+#if defined(RSLAM_DEBUG)
+    const char* v = getenv(name);          // measurement switches exist in the diagnostic variant only
+    if (v && *v) return atoi(v);
+#else
+    (void)name;
+#endif
+    return dflt;
+}
+
+// Streams with disjoint CU masks.  The first cus_S bits of a mask are compute units spread evenly over the XCDs and shader
+// engines (scripts/probes/cu_mask.hip: 32 bits = 4 CUs of each XCD), the next cus_I bits likewise, the R stage gets the rest.
+static bool staged_init(rslam_ctx* c)
+{
+    rslam_ctx::Staged& st = c->staged;
+    if (st.tried) return st.ok;
+    st.tried = true;
+    if (staged_env_int("RSLAM_NO_STAGED", 0)) return false;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int cus = prop.multiProcessorCount;
+    st.cus_S = staged_env_int("RSLAM_STAGED_CUS_S", 32);
+    st.cus_I = staged_env_int("RSLAM_STAGED_CUS_I", 8);
+    if (cus < 128 || st.cus_S < 8 || st.cus_I < 8 || st.cus_S + st.cus_I > cus / 2) return false;
+    const int words = (cus + 31) / 32;
+    std::vector<uint32_t> mS(words, 0), mI(words, 0), mR(words, 0);
+    for (int i = 0; i < cus; ++i) {
+        std::vector<uint32_t>& m = i < st.cus_S ? mS : (i < st.cus_S + st.cus_I ? mI : mR);
+        m[i / 32] |= 1u << (i % 32);
+    }
+    bool ok = hipExtStreamCreateWithCUMask(&st.sS, (uint32_t)words, mS.data()) == hipSuccess
+           && hipExtStreamCreateWithCUMask(&st.sI, (uint32_t)words, mI.data()) == hipSuccess
+           && hipExtStreamCreateWithCUMask(&st.sR, (uint32_t)words, mR.data()) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&st.e0, hipEventDisableTiming) == hipSuccess;
+    for (int g = 0; ok && g < rslam_ctx::Staged::MAX_GROUPS; ++g)
+        ok = hipEventCreateWithFlags(&st.eGrp[g], hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&st.eInv[g], hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&st.eR[g], hipEventDisableTiming) == hipSuccess;
+    ok = ok && init_staged_kernel_attributes() == 0;
+    if (!ok) { (void)hipGetLastError(); staged_release(c); return false; }
+    st.ok = true;
+    return true;
+}
+
+// Group boundaries of an update of nblk column blocks: a short first group (the R stage starts early), the rest so that the
+// S stage is done about when the group before the last leaves the masked stream.  Empty = the route is not taken.
+static std::vector<int> staged_groups(int nblk)
+{
+    std::vector<int> b;
+    const int min_blocks = staged_env_int("RSLAM_STAGED_MIN_BLOCKS", 12);
+    if (nblk < min_blocks || nblk < 4) return b;
+#if defined(RSLAM_DEBUG)
+    if (const char* e = getenv("RSLAM_STAGED_GROUPS")) {          // "4,12": boundaries behind 0, in front of nblk
+        b.push_back(0);
+        for (const char* q = e; *q; ) {
+            const int v = atoi(q);
+            if (v > b.back() && v < nblk && (int)b.size() < rslam_ctx::Staged::MAX_GROUPS) b.push_back(v);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        b.push_back(nblk);
+        return b;
+    }
+#endif
+    const int g0 = 4, g1 = g0 + (2 * (nblk - g0) + 2) / 5;
+    b = {0, g0, g1, nblk};
+    return b;
+}
+
+// One EKF update of a large system on the staged route.  Everything is stream-ordered: the context's stream waits for the
+// side streams before the last group, so what follows it is ordered behind the whole update.
+static int enqueue_staged_update(rslam_ctx* c, const std::vector<int>& grp, const SystemDims& d, int slot_k, int slot_nblk, int nblk,
+                                 const double* x_in, double* x_out, const double* Pin, double* Pout,
+                                 int ev_f1, int ev_r0)
+{
+    rslam_ctx::Staged& st = c->staged;
+    hipStream_t s = c->stream;
+    int32_t* sel = c->d_sel.p;
+    const long ldm = d.RP;
+    if (st.d_M.ensure((size_t)d.RP * d.RP) < 0 || st.d_Mt.ensure((size_t)d.RP * d.RP) < 0) return RSLAM_ERR_HIP;
+    const int G = (int)grp.size() - 1;
+    double* A = c->d_A.p;
+    double* Ys = c->d_Y.p;
+    HIPCHK(hipEventRecord(st.e0, s));                                   // the system is assembled (prepare_system)
+    // ---- S stage: the sweep of the innovation covariance alone, on its own compute units
+    HIPCHK(hipStreamWaitEvent(st.sS, st.e0, 0));
+    int next = 1;                                                       // next group boundary to announce
+    hipError_t ev_err = hipSuccess;
+    launch_s_stage(st.sS, d, sel, slot_k, slot_nblk, nblk, A, Ys, c->d_Linv.p, sel + SEL_STATUS, st.cus_S,
+                   [&](int done) {
+                       while (next <= G && grp[next] <= done) {
+                           const hipError_t e = hipEventRecord(st.eGrp[next - 1], st.sS);
+                           if (e != hipSuccess) ev_err = e;
+                           ++next;
+                       }
+                   });
+    HIPCHK(ev_err);
+    HIPCHK(hipGetLastError());
+    if (next <= G) return RSLAM_ERR_HIP;                                // (every group was announced: the S stage covers nblk blocks)
+    // ---- group inverses, as the S stage finishes each group
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(hipStreamWaitEvent(st.sI, st.eGrp[g], 0));
+        launch_group_inverse(st.sI, grp[g], grp[g + 1] - grp[g], Ys, d.ldA, c->d_Linv.p, st.d_M.p, st.d_Mt.p, ldm);
+        HIPCHK(hipEventRecord(st.eInv[g], st.sI));
+    }
+    // ---- R stage: per group T, Y, one pass of the rank update; the last group on the context's stream (the S stage is over:
+    //      every compute unit), the others on the masked stream beside the S stage
+    const int32_t* order = (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr;
+    double* Tq = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
+    for (int g = 0; g < G; ++g) {
+        const bool last = (g == G - 1);
+        hipStream_t x = last ? s : st.sR;
+        const int b0 = grp[g], nb = grp[g + 1] - grp[g];
+        HIPCHK(hipStreamWaitEvent(x, st.eInv[g], 0));
+        if (last && g > 0) HIPCHK(hipStreamWaitEvent(x, st.eR[g - 1], 0));
+        if (last) { if (ev_f1 >= 0) mark(c, ev_f1); if (ev_r0 >= 0) mark(c, ev_r0); }
+        launch_staged_T(x, d, b0, nb, A, Ys);
+        launch_staged_Y(x, d, b0, nb, A, Ys, st.d_M.p, ldm);
+        XuArgs xu{};
+        xu.mirror_known = (g > 0) ? 1 : 0;
+        xu.token = (slot_k == SEL_K_LI) ? 1 : 2;
+        if (last) {
+            // K9 (x_k_k = x + Y u, quaternion normalisation, Jnorm) rides in the last pass, K11 is its epilogue
+            xu.groups = c->NP / 16;
+            xu.d = d; xu.A = Ys; xu.x_in = x_in; xu.x_out = x_out; xu.T = Tq; xu.compat = c->cfg.compat;
+            xu.flag = sel + SEL_XU_FLAG;
+            xu.riders_first = c->k10_riders_first ? 1 : 0; xu.inject = c->k10_inject;
+        }
+        const MatArgs mat{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p};
+        launch_rank_update(x, c->NP, g == 0 ? Pin : Pout, c->NP, Ys + d.RP + 64L * b0 * d.ldA, d.ldA, sel, slot_nblk, 64 * nb, Pout, c->NP,
+                           order, last ? Tq : nullptr, slot_k, &xu, (g == 0 && slot_k == SEL_K_HI) ? &mat : nullptr);
+        HIPCHK(hipGetLastError());
+        if (!last) HIPCHK(hipEventRecord(st.eR[g], x));
+    }
+    ++st.updates;
+    return RSLAM_OK;
+}
+
 static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int slot_nblk, int host_blocks, const double* Wsrc,
                               const double* H13,
                               const double* z_h, const double* x_in, double* x_out, const double* Pin, double* Pout,
@@ -572,6 +743,16 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
         // Jnorm of the LI update at d_T, of the HI update behind it: the HI pass may still need the LI one (deferred covariance)
         wk.T = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
         wk.defer_flag = sel + SEL_LI_DEFER; wk.Y1 = c->d_Y1.p; wk.ldy1 = c->NP; wk.Ppred = c->d_Ppred.p; wk.T_li = c->d_T.p;
+    }
+    // Large systems whose block count the host knows (launch-per-step route): S stage and R stage side by side
+    if (!persistent && c->RP > 0 && host_blocks <= c->RP / 64 && !(slot_k == SEL_K_LI && c->li_defer_host)) {
+        const std::vector<int> grp = staged_groups(host_blocks);
+        if (!grp.empty() && staged_init(c)) {
+            const int rc = enqueue_staged_update(c, grp, d, slot_k, slot_nblk, host_blocks, x_in, x_out, Pin, Pout, ev_f1, ev_r0);
+            if (rc) return rc;
+            if (ev_r1 >= 0) mark(c, ev_r1);
+            return RSLAM_OK;
+        }
     }
     Ysys = launch_factor_sweep(s, d, sel, slot_k, slot_nblk, host_blocks, c->d_A.p, c->d_Y.p, c->d_Linv.p, sel + SEL_STATUS,
                                persistent ? c->d_sweep_flags.p : nullptr, persistent ? &src : nullptr, fused ? &wk : nullptr);
@@ -1662,7 +1843,7 @@ extern "C" int rslam_update_mode(rslam_ctx* c)
 {
     if (!c) return RSLAM_ERR_ARG;
     SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
-    if (!sweep_is_persistent(c)) return 0;
+    if (!sweep_is_persistent(c)) return c->staged.updates > 0 ? 3 : 0;
     return sweep_fused_eligible(d) ? 2 : 1;
 }
 
