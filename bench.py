@@ -37,10 +37,11 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_bench_c3_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_bench_c3_pmc_summary.csv")
+PMC_SUMMARY_C5 = os.path.join(ROOT, "profiles", "r05_bench_c5_pmc_summary.csv")
 
 
-def pmc_traffic_bytes(kernel_substr):
+def pmc_traffic_bytes(kernel_substr, summary=None, pick=max):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command at C3, profiles/README.md):
     (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reports half the bytes of coalesced reads on
@@ -49,11 +50,12 @@ def pmc_traffic_bytes(kernel_substr):
     try:
         # (a summary of other kernel sources than the ones in the tree would be a stale figure: not reported then;
         #  scripts/collect_profiles.sh writes the digest next to the summary)
-        if open(PMC_SUMMARY[:-4] + ".src_sha256").read().split()[0] != kernel_sources_digest():
+        summary = summary or PMC_SUMMARY
+        if open(summary[:-4] + ".src_sha256").read().split()[0] != kernel_sources_digest():
             return None
-        rows = [r for r in csv.DictReader(open(PMC_SUMMARY)) if kernel_substr in r["kernel"]]
-        fetch = max(float(r["max"]) for r in rows if r["counter"] == "FETCH_SIZE")
-        write = max(float(r["max"]) for r in rows if r["counter"] == "WRITE_SIZE")
+        rows = [r for r in csv.DictReader(open(summary)) if kernel_substr in r["kernel"]]
+        fetch = pick(float(r["max"]) for r in rows if r["counter"] == "FETCH_SIZE")
+        write = pick(float(r["max"]) for r in rows if r["counter"] == "WRITE_SIZE")
         return (2.0 * fetch + write) * 1024.0
     except Exception:
         return None
@@ -63,7 +65,7 @@ def kernel_sources_digest():
     """sha256 over the sources of the kernels the PMC summary describes"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "tile_gemm.h", "kernels.h", "camera_model.h"):
+    for f in ("kernels.hip", "tile_gemm.h", "kernels.h", "camera_model.h", "rank_macro.hip", "tile_gemm128.h", "rank_common.h", "staged_kernels.hip"):
         h.update(open(os.path.join(ROOT, "ransac_slam_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -130,8 +132,8 @@ def cpu_baseline(frame, cfg, sample_iters, seed):
     # what the reference-structure oracle decided and computed on this very frame (all H iterations run): held against the
     # timed context's results by parity_in_run()
     full = (iters_done == H)
-    oracle_result = dict(li=fu["li"], hi=fu["hi"], x_new=fu["x_new"], best_hyp=rr["best_hyp"], best_support=rr["best_support"],
-                         hyps_evaluated=rr["hyps_evaluated"]) if full else None
+    oracle_result = dict(li=fu["li"], hi=fu["hi"], x_new=fu["x_new"], P_new=fu.get("P_new"), best_hyp=rr["best_hyp"],
+                         best_support=rr["best_support"], hyps_evaluated=rr["hyps_evaluated"]) if full else None
     return oracle_result, dict(value=H * m / est_frame_s, unit="hypotheses*features/s", cores=1, kind="port",
                 optimised_cpu_all_cores_ms_per_frame=omp_ms, optimised_cpu_all_cores_threads=omp_threads,
                 optimised_cpu_ms_per_frame=(t5 - t4) * 1e3,
@@ -172,6 +174,18 @@ def parity_in_run(name, timed, ref):
     out["x_new_max_abs_diff"] = dx
     out["x_new_tol"] = 1e-9 * scale
     ok = ok and dx <= 1e-9 * scale
+    # p_k_k (ExtendKF.cpp:608-609,629-634): norm-wise and entry by entry against sqrt(P_ii P_jj), as tests/test_gpu_parity.py
+    if timed.get("P_new") is not None and ref.get("P_new") is not None:
+        Pt, Pr = np.asarray(timed["P_new"]), np.asarray(ref["P_new"])
+        d = np.abs(Pt - Pr)
+        sd = np.sqrt(np.abs(np.diag(Pr)))
+        out["P_new_max_abs_diff_rel_to_max"] = float(d.max() / np.max(np.abs(Pr)))
+        out["P_new_worst_entry_rel_to_sqrt_PiiPjj"] = float(np.max(d / (np.outer(sd, sd) + 1e-300)))
+        out["P_new_tol"] = 1e-9
+        ok = ok and out["P_new_max_abs_diff_rel_to_max"] <= 1e-9 and out["P_new_worst_entry_rel_to_sqrt_PiiPjj"] <= 1e-9
+        out["P_checked"] = True
+    else:
+        out["P_checked"] = False
     out["ok"] = bool(ok)
     return out
 
@@ -257,9 +271,9 @@ class Runner:
             ts.append((time.perf_counter() - t0) * 1e3)
         return ts
 
-    def result(self):
-        res = self.ctx.fetch_results(want_P=False)
-        self.last = res                   # (li / hi / x_new of the last replayed frame: parity_in_run)
+    def result(self, want_P=False):
+        res = self.ctx.fetch_results(want_P=want_P)
+        self.last = res                   # (li / hi / x_new [/ p_k_k] of the last replayed frame: parity_in_run)
         return {k: int(res[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")}
 
 
@@ -380,14 +394,19 @@ def main():
     ctx, frame, ic, m = run.ctx, run.frame, run.ic, run.m
     H_total, H_local = run.H_total, run.H_local
     elapsed = run.timed(args.steps, args.warmup)
-    res = ctx.fetch_results(want_P=False)         # outputs of the LAST frame of the timed region (checked below: parity_in_run)
+    # outputs of the LAST frame of the timed region, p_k_k included (checked below: parity_in_run; outside the timed region)
+    res = ctx.fetch_results(want_P=(world == 1 and not args.no_cpu_baseline))
     parity = []
 
     def config_of(r, wl_):
+        # (frames of the large-system route -- update mode 0 / 3 -- are never captured: the host sizes the launch sequence of
+        #  each update from the frame's own inlier counts, rslam_api.hip enqueue_update)
+        host_sized = r.ctx.update_mode() in (0, 3)
         return {"workload": wl_["name"], "landmarks": wl_["L"], "state_dim": int(r.frame.n),
                 "matched_features": r.m, "hypotheses_total": r.H_total, "hypotheses_per_gpu": r.H_local,
                 "compat": int(r.cfg.compat), "adaptive": 0, "dedup": args.dedup,
-                "launch": ("eager stream" if args.no_graph else
+                "launch": ("eager stream, host-sized launch sequence (update counts read from host-mapped memory)" if host_sized else
+                           "eager stream" if args.no_graph else
                            ("hipGraph replay" if world == 1 else "two hipGraphs per frame around the all-gather")),
                 "parallelism": f"hypothesis-sharded x{world}, replicated update" if world > 1 else "single GPU"}
 
@@ -453,7 +472,7 @@ def main():
         e2 = alt.timed(args.steps, args.warmup)
         if rank == 0:
             out["compat0"] = {"ms_per_step": e2 / args.steps * 1e3, "value": alt.H_total * alt.m * args.steps / e2,
-                              "result": alt.result(), "config": config_of(alt, wl)}
+                              "result": alt.result(want_P=(world == 1 and not args.no_cpu_baseline)), "config": config_of(alt, wl)}
             if world == 1 and not args.no_cpu_baseline:
                 parity.append(parity_in_run("compat0", alt.last, oracle_frame_result(alt.frame, alt.cfg, alt.ic)))
             if world == 1:
@@ -488,14 +507,40 @@ def main():
             r5 = c5.result()
             acc5, out5, _ = eager_stage_times(c5.ctx, 5, warm=3)
             n5 = int(c5.frame.n)
-            us5, rr5 = max((acc5["rank_update_hi_us"], 2 * r5["n_hi"]), (acc5["rank_update_li_us"], 2 * r5["n_li"]))
+            (us5, rr5, fs5, which5) = max((acc5["rank_update_hi_us"], 2 * r5["n_hi"], acc5["factor_hi_us"], "HI"),
+                                          (acc5["rank_update_li_us"], 2 * r5["n_li"], acc5["factor_li_us"], "LI"))
             f5 = float(n5) * (n5 + 1) * rr5
+            f5s = rr5 ** 3 / 3.0 + float(n5) * rr5 * rr5
+            tf5 = f5 / (us5 * 1e-6) * 1e-12 if us5 > 0 else 0.0
+            traffic5 = None
+            if cm == 1 and which5 == "HI":          # (the committed C5 PMC passes are of the reference-faithful mode: its HI update)
+                t_macro = pmc_traffic_bytes("rank_update_macro_kernel", PMC_SUMMARY_C5)
+                t_small = pmc_traffic_bytes("rank_update_kernel<true>", PMC_SUMMARY_C5)
+                if t_macro is not None and t_small is not None:
+                    traffic5 = t_macro + t_small
             line5 = {"ms_per_step": e5 / k5 * 1e3, "steps": k5, "result": r5, "config": config_of(c5, WORKLOADS["C5"]),
                      "stage_us": {kk: round(vv, 1) for kk, vv in acc5.items()}, "outliers": out5,
-                     "rank_update": {"launch_us": us5, "rank_r": rr5, "achieved_TFLOPs": f5 / (us5 * 1e-6) * 1e-12 if us5 > 0 else 0.0,
-                                     "frac_of_fp64_mfma_peak": f5 / (us5 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if us5 > 0 else 0.0},
+                     "rank_update": {"launch_us": us5, "rank_r": rr5, "achieved_TFLOPs": tf5,
+                                     "frac_of_fp64_mfma_peak": tf5 / FP64_MFMA_PEAK_TFLOPS},
+                     # the dominant stage of a C5 frame as a roofline object: the covariance rank update of its larger update
+                     # (x update launch + 128 x 128 macro tiles for whole rounds + 64 x 64 tiles for the rest: three launches
+                     # between the stage's hipEvents); traffic = the three kernels' PMC bytes of the committed C5 passes
+                     "roofline": {"bound": "mfma", "kernel": "rank update of the %s update (rank_update_macro_kernel + rank_update_kernel for the "
+                                                              "last partial round + the x update's launch)" % which5,
+                                  "achieved": tf5, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf5 / FP64_MFMA_PEAK_TFLOPS,
+                                  "launch_us": us5, "rank_r": rr5, "algorithmic_flops_per_launch": f5,
+                                  "algorithmic_bytes_per_launch": 8.0 * (2.0 * n5 * n5 + n5 * rr5),
+                                  "traffic": traffic5,
+                                  "traffic_note": "HBM bytes of the macro-tile launch + the 64 x 64 launch of the same pass (2 x FETCH_SIZE + "
+                                                  "WRITE_SIZE KiB, profiles/r05_bench_c5_pmc_summary.csv; null when older than the kernels)"},
+                     "factor_sweep": {"launch_us": fs5, "rank_r": rr5, "algorithmic_flops": f5s,
+                                      "achieved_TFLOPs": f5s / (fs5 * 1e-6) * 1e-12 if fs5 > 0 else 0.0,
+                                      "frac_of_fp64_mfma_peak": f5s / (fs5 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if fs5 > 0 else 0.0,
+                                      "note": "r^3/3 + n r^2 flop of the blocked Cholesky sweep over its stage time (system assembly + "
+                                              "25 pivot chains in 38 launches: latency-bound)"},
                      "update_mode": c5.ctx.update_mode(),
-                     "note": "too large for the persistent sweep (508 strips > CUs): launch-per-step sweep + stand-alone rank update"}
+                     "note": "too large for the persistent sweep (508 strips > CUs): launch-per-step sweep sized by the host + rank update "
+                             "as launches of its own"}
             if cm == args.compat:
                 out["c5"].update(line5)
             else:
@@ -661,6 +706,21 @@ def main():
                                         "oracle on the same inputs: best_hyp / best_support / hyps_evaluated / LI / HI sets bit-exact, "
                                         "x_k_k within 1e-9 * max(1, |x|); the oracle runs outside the timed regions"}
     if rank == 0:
+        # the figures a reader looks for first, flat, at the front of the line (the driver's parser keeps the head and the tail)
+        summ = {"c3_ms_per_step": out["ms_per_step"] if args.workload == "C3" else None,
+                "c3_compat0_ms_per_step": out.get("compat0", {}).get("ms_per_step"),
+                "c4_ms_per_step": out.get("c4", {}).get("ms_per_step"),
+                "c4_compat0_ms_per_step": out.get("c4", {}).get("compat0", {}).get("ms_per_step"),
+                "c5_ms_per_step": out.get("c5", {}).get("ms_per_step") if args.workload != "C5" else out["ms_per_step"],
+                "c5_compat0_ms_per_step": out.get("c5", {}).get("compat0", {}).get("ms_per_step"),
+                "c5_rank_update_frac": out.get("c5", {}).get("roofline", {}).get("frac"),
+                "c5_factor_sweep_frac": out.get("c5", {}).get("factor_sweep", {}).get("frac_of_fp64_mfma_peak"),
+                "roofline_frac": out.get("roofline", {}).get("frac"),
+                "parity_ok": out.get("parity_in_run", {}).get("ok")}
+        head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}
+        head["summary"] = summ
+        head.update({k: v for k, v in out.items() if k not in head})
+        out = head
         print(json.dumps(out))
     ctx.close()
     if rank == 0 and "parity_in_run" in out and not out["parity_in_run"]["ok"]:

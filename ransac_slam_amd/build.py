@@ -19,8 +19,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librslam_hip.so")
 LIB_DEBUG = os.path.join(HERE, "librslam_hip_dbg.so")
-SOURCES = ["kernels.hip", "staged_kernels.hip", "map_kernels.hip", "match_kernels.hip", "rslam_api.hip"]
-HEADERS = ["kernels.h", "tile_gemm.h", "camera_model.h", os.path.join("..", "..", "include", "rslam.h")]
+SOURCES = ["kernels.hip", "staged_kernels.hip", "rank_macro.hip", "map_kernels.hip", "match_kernels.hip", "rslam_api.hip"]
+HEADERS = ["kernels.h", "tile_gemm.h", "tile_gemm128.h", "rank_common.h", "camera_model.h", os.path.join("..", "..", "include", "rslam.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -129,7 +129,7 @@ def build_dev(name, extra_flags=(), full=False):
     objs = []
     jobs = []
     for src in SOURCES:
-        if src in ("kernels.hip", "rslam_api.hip"):
+        if src in ("kernels.hip", "rslam_api.hip", "rank_macro.hip", "staged_kernels.hip"):
             o = os.path.join(OBJ, "dev_%s_%s.o" % (name, os.path.splitext(src)[0]))
             jobs.append([_hipcc()] + FLAGS + flags + ["-c", os.path.join(CSRC, src), "-o", o])
         else:
@@ -137,7 +137,7 @@ def build_dev(name, extra_flags=(), full=False):
                 _compile((src, True, ()))
             o = _obj_path(src, True)
         objs.append(o)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(subprocess.check_call, jobs))
     lib = os.path.join(DEV_DIR, name + ".so")
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])

@@ -177,14 +177,22 @@ void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, cons
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
                         const int32_t* tile_order /* nullable: row-major triangle */,
                         const double* Tq /* nullable: 4 x 4 Jnorm, applied to rows/columns 3..6 (K11) when sel[slot_k] != 0 */,
-                        int slot_k, const XuArgs* xu /* nullable */, const MatArgs* mat = nullptr /* HI pass: P_li may be deferred */);
+                        int slot_k, const XuArgs* xu /* nullable */, const MatArgs* mat = nullptr /* HI pass: P_li may be deferred */,
+                        int n_tiles = -1 /* >= 0: only the first n_tiles entries of tile_order */);
+// rank_macro.hip: the same update on 128 x 128 macro tiles (large maps; whole rounds of one workgroup per compute unit, the
+// rest of the triangle is left to launch_rank_update with the `small` list)
+void make_macro_order(int nT, int cus, std::vector<int32_t>& macro, std::vector<int32_t>& small);
+void launch_rank_update_macro(hipStream_t s, const double* Pin, long ldp, const double* Y, long ldy, int K, double* Pout, long ldo,
+                              const int32_t* macro_order, int n_macro, const int32_t* sel, int slot_k, const double* Tq,
+                              int mirror_flag, int token, const MatArgs* mat);
+int init_macro_kernel_attributes();
 void make_rank_update_order(int nT, std::vector<int32_t>& order);   // XCD-aware (bi << 16 | bj) per block
 
 // ---- the staged route of large systems (staged_kernels.hip; S stage in kernels.hip) ----
 void launch_s_stage(hipStream_t s, const SystemDims& d, const int32_t* sel, int slot_k, int slot_nblk, int steps,
                     double* A, double* Ystore, double* Linv, int32_t* status_sel, int cus, const std::function<void(int)>& progress);
 void launch_group_inverse(hipStream_t s, int b0, int nb, const double* Lp, long ldl, const double* Linv, double* M, double* Mt, long ldm);
-void launch_staged_T(hipStream_t s, const SystemDims& d, int b0, int nb, double* A, const double* Ystore);
+void launch_staged_update(hipStream_t s, const SystemDims& d, int b0, int nb, int nblk, double* A, const double* Ystore);
 void launch_staged_Y(hipStream_t s, const SystemDims& d, int b0, int nb, const double* A, double* Ystore, const double* M, long ldm);
 int init_staged_kernel_attributes();
 

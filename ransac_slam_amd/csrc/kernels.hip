@@ -14,6 +14,7 @@
 // K12 rescue_gate_kernel    chi-square gate of the high-innovation candidates
 #include "kernels.h"
 #include "tile_gemm.h"
+#include "rank_common.h"
 #include <vector>
 #include <type_traits>
 #include <cstddef>
@@ -4031,53 +4032,7 @@ __device__ __forceinline__ void xupdate_rows(int group, SystemDims d, const int3
 // = ExtendKF.cpp:608-609 (P - K S K^T, then 1/2 (P + P^T)) with K S K^T = Y Y^T.
 // Safe in place: a workgroup owns both tiles of its pair.
 // ---------------------------------------------------------------------------
-// The Jnorm congruence (ExtendKF.cpp:629-634) on an LDS tile Cs[col][row] of the first block column: tile (bi, 0) has its
-// columns 3..6 mixed, tile (0, 0) rows and columns (its 4 x 4 block symmetrised afterwards, as the reader of an immediate P_li
-// would see it); every thread of the 256 calls it; ends behind a barrier.
-__device__ __forceinline__ void k11_lds(double* Cs, const double (&T)[16], int bi)
-{
-    const int j = threadIdx.x;
-    if (bi != 0) {
-        if (j < 64) {
-            double rb[4];
-            for (int i = 0; i < 4; ++i) {
-                double sacc = 0;
-                for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + k) * TS_LD + j];
-                rb[i] = sacc;
-            }
-            for (int i = 0; i < 4; ++i) Cs[(3 + i) * TS_LD + j] = rb[i];
-        }
-    } else {
-        if (j < 64 && !(j >= 3 && j < 7)) {
-            double rb[4];
-            for (int i = 0; i < 4; ++i) {
-                double sacc = 0;
-                for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[j * TS_LD + (3 + k)];
-                rb[i] = sacc;
-            }
-            for (int i = 0; i < 4; ++i) { Cs[j * TS_LD + (3 + i)] = rb[i]; Cs[(3 + i) * TS_LD + j] = rb[i]; }
-        } else if (j == 3) {
-            double cb[4][4], out[4][4];         // cb = J * P44 ; out = cb * J^T
-            for (int i = 0; i < 4; ++i)
-                for (int c = 0; c < 4; ++c) {
-                    double sacc = 0;
-                    for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + c) * TS_LD + (3 + k)];
-                    cb[i][c] = sacc;
-                }
-            for (int i = 0; i < 4; ++i)
-                for (int c = 0; c < 4; ++c) {
-                    double sacc = 0;
-                    for (int k = 0; k < 4; ++k) sacc += cb[i][k] * T[c + 4 * k];
-                    out[i][c] = sacc;
-                }
-            // (the pass that reads an immediate P_li takes 1/2 (P + P^T) of what the congruence left: the same here)
-            for (int i = 0; i < 4; ++i)
-                for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = 0.5 * out[i][c] + 0.5 * out[c][i];
-        }
-    }
-    __syncthreads();
-}
-
+// (k11_lds, the Jnorm congruence on an LDS tile of the first block column: rank_common.h)
 // MAT: the pass may have to start from a deferred P_li (MatArgs); an instantiation of its own so that the plain pass keeps its
 // register count (two workgroups per compute unit)
 template <bool MAT>
@@ -4321,10 +4276,11 @@ static unsigned long long* k10_dbg_buffer() { return nullptr; }
 
 void launch_rank_update(hipStream_t s, int NP, const double* Pin, long ldp, const double* Y, long ldy,
                         const int32_t* sel, int slot_nblk, int fixed_k, double* Pout, long ldo,
-                        const int32_t* tile_order, const double* Tq, int slot_k, const XuArgs* xu, const MatArgs* mat)
+                        const int32_t* tile_order, const double* Tq, int slot_k, const XuArgs* xu, const MatArgs* mat,
+                        int n_tiles /* >= 0: only the first n_tiles entries of tile_order (the tiles a macro-tile launch left over) */)
 {
     const int nT = NP / 64;
-    int tiles = nT * (nT + 1) / 2;
+    int tiles = (n_tiles >= 0 && tile_order) ? n_tiles : nT * (nT + 1) / 2;
     if (tiles <= 0) return;
     XuArgs none{}; none.groups = 0;
     const XuArgs& x = xu ? *xu : none;

@@ -72,6 +72,10 @@ struct rslam_ctx {
     // device buffers
     DevBuf<uint8_t> d_type, d_vis, d_hash, d_hash2, d_ic, d_li, d_hi, d_mtype;
     DevBuf<int32_t> d_tile_order;
+    // rank update of large maps on 128 x 128 macro tiles (rank_macro.hip): tile lists for the current nT
+    DevBuf<int32_t> d_macro_order, d_small_order;
+    int macro_nT = 0, n_macro = 0, n_small = 0;
+    bool macro_attr = false;
     bool li_defer_host = false;                  // this frame's LI update (stand-alone path) leaves its covariance deferred
     int tile_order_nT = 0;
     DevBuf<int32_t> d_off, d_mfeat, d_moff, d_mith, d_miph, d_mzsrc, d_rank_of, d_pos, d_nhyp,
@@ -133,7 +137,7 @@ struct rslam_ctx {
         bool tried = false, ok = false;
         hipStream_t sS = nullptr, sI = nullptr, sR = nullptr;
         int cus_S = 0, cus_I = 0;
-        static constexpr int MAX_GROUPS = 8;
+        static constexpr int MAX_GROUPS = 16;
         hipEvent_t e0 = nullptr, eGrp[MAX_GROUPS] = {}, eInv[MAX_GROUPS] = {}, eR[MAX_GROUPS] = {};
         DevBuf<double> d_M, d_Mt;      // group inverses L_gg^-1 (RP x RP, the groups' diagonal blocks) and their transposes
         int updates = 0;               // updates that took the route (rslam_update_mode reports it)
@@ -143,6 +147,7 @@ struct rslam_ctx {
 // bookkeeping of every path that puts an update stage on the stream (eager or graph replay)
 static void unpin_host_buffers(rslam_ctx* c);
 static void staged_release(rslam_ctx* c);
+static int staged_env_int(const char* name, int dflt);
 static bool sweep_is_persistent(const rslam_ctx* c)
 {
     if (c->steps_frames_left > 0) return false;      // a hand-over of the persistent sweep timed out recently (see read_status)
@@ -265,7 +270,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_W.release(); c->d_A.release(); c->d_Y.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
-    c->d_sup_local.release(); c->d_sup_all.release();
+    c->d_sup_local.release(); c->d_sup_all.release(); c->d_macro_order.release(); c->d_small_order.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     unpin_host_buffers(c);
@@ -556,6 +561,62 @@ static const int32_t* tile_order(rslam_ctx* c, int NP)
 }
 
 
+
+// Tile lists of the macro-tile rank update for the current map size (built once per size); false: not for this size
+static bool macro_lists(rslam_ctx* c)
+{
+    const int nT = c->NP / 64;
+    if (nT < 32) return false;                             // small maps: the fused persistent sweep or the 64 x 64 form
+    if (staged_env_int("RSLAM_NO_MACRO", 0)) return false;   // (measurement; diagnostic variant only)
+    if (!c->macro_attr) {
+        if (init_macro_kernel_attributes() != 0) { (void)hipGetLastError(); return false; }
+        c->macro_attr = true;
+    }
+    if (c->macro_nT != nT) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+        std::vector<int32_t> macro, small;
+        make_macro_order(nT, prop.multiProcessorCount, macro, small);
+        if (c->d_macro_order.ensure(macro.size()) < 0 || c->d_small_order.ensure(small.size()) < 0) return false;
+        if (!macro.empty() && hipMemcpy(c->d_macro_order.p, macro.data(), sizeof(int32_t) * macro.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+        if (!small.empty() && hipMemcpy(c->d_small_order.p, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+        c->macro_nT = nT; c->n_macro = (int)macro.size(); c->n_small = (int)small.size();
+    }
+    return c->n_macro > 0;
+}
+
+// One pass P' = sym(P) - Y(:, k0 .. k0 + K) Y(..)^T of an update whose width the host knows (large-map route), on stream x:
+// macro tiles for whole rounds + the 64 x 64 form for the rest when the map is large enough, else the 64 x 64 form alone.
+// `xu` (nullable): the x update of the LAST pass -- it rides in the 64 x 64 launch, or runs as a launch of its own in front of
+// the macro tiles (whose first block column then finds Jnorm written).
+static int enqueue_rank_pass(rslam_ctx* c, hipStream_t x, const double* Pin, double* Pout, const double* Ycols, long ldy, int K,
+                             int slot_k, int slot_nblk, const double* Tq, const XuArgs* xu, const MatArgs* mat, int mirror_flag)
+{
+    int32_t* sel = c->d_sel.p;
+    const int32_t* order = (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr;
+    XuArgs plain{};
+    plain.mirror_known = mirror_flag;
+    plain.token = (slot_k == SEL_K_LI) ? 1 : 2;
+    if (K > 0 && K % 64 == 0 && macro_lists(c)) {
+        if (xu && xu->groups > 0) {
+            XuArgs alone = *xu;
+            alone.riders_only = 1; alone.Y1out = nullptr; alone.defer_flag = nullptr;
+            launch_rank_update(x, c->NP, Pin, c->NP, Ycols, ldy, sel, slot_nblk, K, Pout, c->NP, order, nullptr, slot_k, &alone, nullptr);
+        }
+        launch_rank_update_macro(x, Pin, c->NP, Ycols, ldy, K, Pout, c->NP, c->d_macro_order.p, c->n_macro, sel, slot_k, Tq,
+                                 mirror_flag, plain.token, mat);
+        if (c->n_small > 0)
+            launch_rank_update(x, c->NP, Pin, c->NP, Ycols, ldy, sel, slot_nblk, K, Pout, c->NP, c->d_small_order.p, Tq, slot_k, &plain, mat,
+                               c->n_small);
+    } else {
+        XuArgs with = xu ? *xu : plain;
+        with.mirror_known = mirror_flag;
+        launch_rank_update(x, c->NP, Pin, c->NP, Ycols, ldy, sel, slot_nblk, K, Pout, c->NP, order, Tq, slot_k, &with, mat);
+    }
+    HIPCHK(hipGetLastError());
+    return RSLAM_OK;
+}
+
 // ------------------------------------------------------------------------
 // Staged route of large systems (see staged_kernels.hip)
 // ------------------------------------------------------------------------
@@ -618,33 +679,36 @@ static bool staged_init(rslam_ctx* c)
     return true;
 }
 
-// Group boundaries of an update of nblk column blocks: a short first group (the R stage starts early), the rest so that the
-// S stage is done about when the group before the last leaves the masked stream.  Empty = the route is not taken.
+// Group boundaries of the blocked substitution of an update of nblk column blocks (groups of four diagonal blocks; a short
+// last group joins the one before).  Empty = the route is not taken.
 static std::vector<int> staged_groups(int nblk)
 {
     std::vector<int> b;
-    const int min_blocks = staged_env_int("RSLAM_STAGED_MIN_BLOCKS", 12);
-    if (nblk < min_blocks || nblk < 4) return b;
-#if defined(RSLAM_DEBUG)
-    if (const char* e = getenv("RSLAM_STAGED_GROUPS")) {          // "4,12": boundaries behind 0, in front of nblk
-        b.push_back(0);
-        for (const char* q = e; *q; ) {
-            const int v = atoi(q);
-            if (v > b.back() && v < nblk && (int)b.size() < rslam_ctx::Staged::MAX_GROUPS) b.push_back(v);
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
-        b.push_back(nblk);
-        return b;
-    }
-#endif
-    const int g0 = 4, g1 = g0 + (2 * (nblk - g0) + 2) / 5;
-    b = {0, g0, g1, nblk};
+    // Measured in round 5 (scripts/ab_c5.py, C5): with the launch-per-step S stage the route is SLOWER than the plain
+    // launch-per-step sweep (2.47 against 2.10 ms per frame: the S stage alone takes 630-700 us on its compute units -- 25
+    // pivot chains of ~19 us in 38 launches -- and the last group's inverse and solve stand behind it), so the product never
+    // takes it; the diagnostic variant does when RSLAM_STAGED_MIN_BLOCKS says so (tests hold it to the oracle).  It needs the
+    // one-launch S stage (the persistent chain at 13 us per block) to pay: NOTEBOOK.md, round 5.
+    const int min_blocks = staged_env_int("RSLAM_STAGED_MIN_BLOCKS", 1 << 20);
+    const int gs = staged_env_int("RSLAM_STAGED_GROUP", 4);
+    if (nblk < min_blocks || nblk < 4 || gs < 1) return b;
+    // the LAST group is short (its inverse and its solve stand between the end of the S stage and the rank update): the
+    // groups are counted from the end, the first one takes the remainder
+    const int tail = staged_env_int("RSLAM_STAGED_TAIL", 2);
+    std::vector<int> rev;
+    int k = nblk - tail;
+    rev.push_back(nblk);
+    for (; k > gs / 2; k -= gs) rev.push_back(k);
+    rev.push_back(0);
+    b.assign(rev.rbegin(), rev.rend());
+    if ((int)b.size() - 1 > rslam_ctx::Staged::MAX_GROUPS) b.clear();
     return b;
 }
 
-// One EKF update of a large system on the staged route.  Everything is stream-ordered: the context's stream waits for the
-// side streams before the last group, so what follows it is ordered behind the whole update.
+// One EKF update of a large system on the staged route.  Everything is stream-ordered; the host enqueues each group's
+// inverse / solve / update right behind the S-stage launch that finishes the group (a stream only starts what has been
+// enqueued: with the whole S stage enqueued first the other streams' first launches came ~400 us late).  The context's
+// stream waits for the side streams before the rank update, so what follows it is ordered behind the whole update.
 static int enqueue_staged_update(rslam_ctx* c, const std::vector<int>& grp, const SystemDims& d, int slot_k, int slot_nblk, int nblk,
                                  const double* x_in, double* x_out, const double* Pin, double* Pout,
                                  int ev_f1, int ev_r0)
@@ -658,56 +722,45 @@ static int enqueue_staged_update(rslam_ctx* c, const std::vector<int>& grp, cons
     double* A = c->d_A.p;
     double* Ys = c->d_Y.p;
     HIPCHK(hipEventRecord(st.e0, s));                                   // the system is assembled (prepare_system)
-    // ---- S stage: the sweep of the innovation covariance alone, on its own compute units
     HIPCHK(hipStreamWaitEvent(st.sS, st.e0, 0));
     int next = 1;                                                       // next group boundary to announce
-    hipError_t ev_err = hipSuccess;
+    hipError_t err = hipSuccess;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; };
+    // ---- S stage: the sweep of the innovation covariance alone, on its own compute units; behind the launch that finishes a
+    //      group: its inverse (stream sI) and, behind that, Y_g = W_g M_g^T and the update of every later column block (stream sR)
     launch_s_stage(st.sS, d, sel, slot_k, slot_nblk, nblk, A, Ys, c->d_Linv.p, sel + SEL_STATUS, st.cus_S,
                    [&](int done) {
                        while (next <= G && grp[next] <= done) {
-                           const hipError_t e = hipEventRecord(st.eGrp[next - 1], st.sS);
-                           if (e != hipSuccess) ev_err = e;
+                           const int g = next - 1, b0 = grp[g], nb = grp[g + 1] - grp[g];
+                           chk(hipEventRecord(st.eGrp[g], st.sS));
+                           chk(hipStreamWaitEvent(st.sI, st.eGrp[g], 0));
+                           launch_group_inverse(st.sI, b0, nb, Ys, d.ldA, c->d_Linv.p, st.d_M.p, st.d_Mt.p, ldm);
+                           chk(hipEventRecord(st.eInv[g], st.sI));
+                           chk(hipStreamWaitEvent(st.sR, st.eInv[g], 0));
+                           launch_staged_Y(st.sR, d, b0, nb, A, Ys, st.d_M.p, ldm);
+                           launch_staged_update(st.sR, d, b0, nb, nblk, A, Ys);
                            ++next;
                        }
                    });
-    HIPCHK(ev_err);
+    HIPCHK(err);
     HIPCHK(hipGetLastError());
     if (next <= G) return RSLAM_ERR_HIP;                                // (every group was announced: the S stage covers nblk blocks)
-    // ---- group inverses, as the S stage finishes each group
-    for (int g = 0; g < G; ++g) {
-        HIPCHK(hipStreamWaitEvent(st.sI, st.eGrp[g], 0));
-        launch_group_inverse(st.sI, grp[g], grp[g + 1] - grp[g], Ys, d.ldA, c->d_Linv.p, st.d_M.p, st.d_Mt.p, ldm);
-        HIPCHK(hipEventRecord(st.eInv[g], st.sI));
-    }
-    // ---- R stage: per group T, Y, one pass of the rank update; the last group on the context's stream (the S stage is over:
-    //      every compute unit), the others on the masked stream beside the S stage
-    const int32_t* order = (c->tile_order_nT == c->NP / 64) ? c->d_tile_order.p : nullptr;
+    HIPCHK(hipEventRecord(st.eR[0], st.sR));
+    // ---- the covariance: one pass over the whole width on every compute unit, K9 with it, K11 its epilogue
+    HIPCHK(hipStreamWaitEvent(s, st.eR[0], 0));
+    if (ev_f1 >= 0) mark(c, ev_f1);
+    if (ev_r0 >= 0) mark(c, ev_r0);
     double* Tq = c->d_T.p + (slot_k == SEL_K_LI ? 0 : 16);
-    for (int g = 0; g < G; ++g) {
-        const bool last = (g == G - 1);
-        hipStream_t x = last ? s : st.sR;
-        const int b0 = grp[g], nb = grp[g + 1] - grp[g];
-        HIPCHK(hipStreamWaitEvent(x, st.eInv[g], 0));
-        if (last && g > 0) HIPCHK(hipStreamWaitEvent(x, st.eR[g - 1], 0));
-        if (last) { if (ev_f1 >= 0) mark(c, ev_f1); if (ev_r0 >= 0) mark(c, ev_r0); }
-        launch_staged_T(x, d, b0, nb, A, Ys);
-        launch_staged_Y(x, d, b0, nb, A, Ys, st.d_M.p, ldm);
-        XuArgs xu{};
-        xu.mirror_known = (g > 0) ? 1 : 0;
-        xu.token = (slot_k == SEL_K_LI) ? 1 : 2;
-        if (last) {
-            // K9 (x_k_k = x + Y u, quaternion normalisation, Jnorm) rides in the last pass, K11 is its epilogue
-            xu.groups = c->NP / 16;
-            xu.d = d; xu.A = Ys; xu.x_in = x_in; xu.x_out = x_out; xu.T = Tq; xu.compat = c->cfg.compat;
-            xu.flag = sel + SEL_XU_FLAG;
-            xu.riders_first = c->k10_riders_first ? 1 : 0; xu.inject = c->k10_inject;
-        }
-        const MatArgs mat{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p};
-        launch_rank_update(x, c->NP, g == 0 ? Pin : Pout, c->NP, Ys + d.RP + 64L * b0 * d.ldA, d.ldA, sel, slot_nblk, 64 * nb, Pout, c->NP,
-                           order, last ? Tq : nullptr, slot_k, &xu, (g == 0 && slot_k == SEL_K_HI) ? &mat : nullptr);
-        HIPCHK(hipGetLastError());
-        if (!last) HIPCHK(hipEventRecord(st.eR[g], x));
-    }
+    XuArgs xu{};
+    xu.token = (slot_k == SEL_K_LI) ? 1 : 2;
+    xu.groups = c->NP / 16;
+    xu.d = d; xu.A = Ys; xu.x_in = x_in; xu.x_out = x_out; xu.T = Tq; xu.compat = c->cfg.compat;
+    xu.flag = sel + SEL_XU_FLAG;
+    xu.riders_first = c->k10_riders_first ? 1 : 0; xu.inject = c->k10_inject;
+    const MatArgs mat{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p};
+    const int rc = enqueue_rank_pass(c, s, Pin, Pout, Ys + d.RP, d.ldA, 64 * nblk, slot_k, slot_nblk, Tq, &xu,
+                                     slot_k == SEL_K_HI ? &mat : nullptr, 0);
+    if (rc) return rc;
     ++st.updates;
     return RSLAM_OK;
 }
@@ -774,8 +827,15 @@ static int enqueue_one_update(rslam_ctx* c, const int32_t* list, int slot_k, int
             xu.riders_only = 1; xu.Y1out = c->d_Y1.p; xu.ldy1 = c->NP; xu.defer_flag = sel + SEL_LI_DEFER;
         }
         const MatArgs mat{sel + SEL_LI_DEFER, c->d_Ppred.p, c->NP, c->d_Y1.p, c->NP, c->d_T.p};
-        launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
-                           order, c->RP > 0 ? Tq : nullptr, slot_k, &xu, slot_k == SEL_K_HI ? &mat : nullptr);
+        if (!persistent && !xu.riders_only && c->RP > 0 && host_blocks > 0 && host_blocks <= c->RP / 64) {
+            // the host knows this update's width (launch-per-step route): large maps take the macro-tile form
+            const int rc = enqueue_rank_pass(c, s, Pin, Pout, Ysys + c->RP, c->ldA, 64 * host_blocks, slot_k, slot_nblk, Tq, &xu,
+                                             slot_k == SEL_K_HI ? &mat : nullptr, 0);
+            if (rc) return rc;
+        } else {
+            launch_rank_update(s, c->NP, Pin, c->NP, Ysys + c->RP, c->ldA, sel, slot_nblk, c->RP > 0 ? -1 : 0, Pout, c->NP,
+                               order, c->RP > 0 ? Tq : nullptr, slot_k, &xu, slot_k == SEL_K_HI ? &mat : nullptr);
+        }
     }
     if (ev_r1 >= 0) mark(c, ev_r1);
     return RSLAM_OK;

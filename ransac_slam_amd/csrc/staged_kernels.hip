@@ -6,11 +6,12 @@
 //   R stage   everything that has n = 6013 rows and is MFMA work, per GROUP g of column blocks [b0, b1) of the factor, as
 //             soon as the S stage has finished that group:
 //               M_g   = L_gg^-1                               group_inverse_kernel   (the group's diagonal block of L, G x G)
-//               T_g   = W_g - sum_{h<g} Y_h L(g,h)^T           staged_gemm_kernel     (W = [P H^T; nu^T]: 6077 rows)
-//               Y_g   = T_g M_g^T                              staged_gemm_kernel     (triangular: K = 64 .. G)
-//               P    -= Y_g Y_g^T                              rank_update_kernel     (one pass over P per group)
-//             i.e. the triangular solve Y L^T = W of the right-looking sweep as a blocked forward substitution whose block
-//             size is a GROUP (512 columns and more), every product a GEMM with K >= 256 at the rate of the rank update.
+//               Y_g   = W_g M_g^T                              staged_gemm_kernel     (W = [P H^T; nu^T]: 6077 rows; triangular)
+//               W_k  -= Y_g L(k,g)^T  for every later block k  staged_gemm_kernel     (right-looking: K = 64 x group size)
+//             i.e. the triangular solve Y L^T = W of the sweep as a blocked forward substitution whose block is a GROUP of four
+//             diagonal blocks, beside the S stage; then ONE pass P -= Y Y^T over the whole width on every compute unit
+//             (rank_macro.hip).  (Round 5 also ran one rank-update pass per group beside the S stage: each pass moves P once
+//             more, and at K = 256 .. 512 a pass runs at 29 .. 35 TFLOP/s -- slower in sum than the single pass, NOTEBOOK.md.)
 //
 // Until round 4 the sweep carried the 6077 rows of W through all 25 block steps (launch per step: 13 narrow passes that
 // leave half the chip idle, 12 wide passes at 38 % MFMA-busy, 0.79 ms) and the rank update (1.05 ms) started when it
@@ -155,16 +156,20 @@ static void launch_staged_gemm(hipStream_t s, const StagedGemm& p)
     staged_gemm_kernel<<<dim3(8 * per_x * p.nb), dim3(256), sizeof(double) * TG_LDS_DOUBLES, s>>>(p);
 }
 
-// T_g = W_g - Y(:, 0 .. b0) L(g, 0 .. b0)^T, in place in the system matrix A (rows RP ..: P H^T and nu^T)
-void launch_staged_T(hipStream_t s, const SystemDims& d, int b0, int nb, double* A, const double* Ystore)
+// Right-looking step of the blocked substitution: the solved group g = [b0, b0 + nb) goes onto every later column block,
+// W(:, k) -= Y_g L(k, g)^T for k = b1 .. nblk - 1, in place in the system matrix A (rows RP ..: P H^T and nu^T).  K = 64 nb:
+// short products, but they run beside the S stage on compute units it does not use, and the LAST group then only waits
+// for its own inverse and one product (left-looking, its T would be a K = 1472 product behind the end of the S stage).
+void launch_staged_update(hipStream_t s, const SystemDims& d, int b0, int nb, int nblk, double* A, const double* Ystore)
 {
-    if (b0 <= 0) return;
+    const int b1 = b0 + nb;
+    if (b1 >= nblk) return;
     StagedGemm p{};
-    p.A = Ystore + d.RP; p.lda = d.ldA;
-    p.B = Ystore + 64L * b0; p.ldb = d.ldA;
-    p.Cin = A + d.RP + 64L * b0 * d.ldA; p.ldi = d.ldA;
-    p.Cout = A + d.RP + 64L * b0 * d.ldA; p.ldo = d.ldA;
-    p.row_tiles = (d.NP + 64) / 64; p.nb = nb; p.k_fixed = 64 * b0; p.tri = 0; p.alpha = -1.0;
+    p.A = Ystore + d.RP + 64L * b0 * d.ldA; p.lda = d.ldA;
+    p.B = Ystore + 64L * b1 + 64L * b0 * d.ldA; p.ldb = d.ldA;
+    p.Cin = A + d.RP + 64L * b1 * d.ldA; p.ldi = d.ldA;
+    p.Cout = A + d.RP + 64L * b1 * d.ldA; p.ldo = d.ldA;
+    p.row_tiles = (d.NP + 64) / 64; p.nb = nblk - b1; p.k_fixed = 64 * nb; p.tri = 0; p.alpha = -1.0;
     launch_staged_gemm(s, p);
 }
 

@@ -547,11 +547,7 @@ def test_large_system_route_against_oracle(hip, oracle_lib):
         o, g, r0, r1 = run_both(hip, oracle_lib, fr, cfg, structure=1)
         check_frame(o, g, r0, r1)
         n_li, n_hi = int(r1["li"].sum()), int(r1["hi"].sum())
-        # the route of the large systems; an update of 12 and more column blocks takes its staged form (S stage beside R stage:
-        # staged_kernels.hip) -- the compat-mode HI update here (13 blocks), neither update of the corrected mode
-        staged = max((2 * n_li + 63) // 64, (2 * n_hi + 63) // 64) >= 12
-        assert g.debug_update_mode() == (3 if staged else 0)
-        assert staged == (compat == 1)
+        assert g.debug_update_mode() == 0                       # the launch-per-step route
         if compat == 1:
             assert 1 <= n_li <= 2 and n_hi > 100                # the deferred low-innovation covariance
         else:
@@ -559,6 +555,54 @@ def test_large_system_route_against_oracle(hip, oracle_lib):
         c = g.counters()
         assert c["sweep_reruns"] == 0 and c["graph_captures"] == 0
         g.close()
+
+
+def test_large_system_staged_route_against_oracle(hip_dbg, oracle_lib):
+    """The staged form of the large-system route (staged_kernels.hip: the factor sweep of the innovation covariance alone on a
+    CU-masked stream, the solve of P H^T L^-T group by group beside it -- group inverse, Y_g = W_g M_g^T, right-looking update
+    of the later blocks --, then one rank update): measured slower than the launch-per-step sweep in round 5, so only the
+    diagnostic library takes it (RSLAM_STAGED_MIN_BLOCKS); held to the oracle here so that it stays a working alternative.
+    500 landmarks: the compat-mode HI update has 13 column blocks (groups 0-3-7-11-13), the corrected mode's LI update 7."""
+    fr = make_frame(L=500, H=300, seed=11)
+    os.environ["RSLAM_STAGED_MIN_BLOCKS"] = "6"
+    try:
+        for compat in (1, 0):
+            cfg = default_config(compat=compat, adaptive=0)
+            o, g, r0, r1 = run_both(hip_dbg, oracle_lib, fr, cfg, structure=1)
+            assert g.debug_update_mode() == 3                   # a staged update has run
+            check_frame(o, g, r0, r1)
+            assert g.counters()["sweep_reruns"] == 0
+            g.close()
+    finally:
+        os.environ.pop("RSLAM_STAGED_MIN_BLOCKS", None)
+
+
+def test_macro_tile_rank_update_equals_64x64_form(hip_dbg):
+    """Large maps run the covariance rank update on 128 x 128 macro tiles (rank_macro.hip: whole rounds of one workgroup per
+    compute unit, the rest of the triangle on the 64 x 64 form).  Same products summed in the same order per entry: the
+    posterior must be BIT-identical to the 64 x 64 form's (RSLAM_NO_MACRO in the diagnostic library) -- both arithmetic
+    modes at 600 landmarks (57 block rows: an odd count, the last block row goes to the 64 x 64 form as well)."""
+    fr = make_frame(L=600, H=100, seed=21)
+    for compat in (1, 0):
+        cfg = default_config(compat=compat, adaptive=0)
+        res = []
+        for no_macro in (False, True):
+            if no_macro:
+                os.environ["RSLAM_NO_MACRO"] = "1"
+            try:
+                g = hip_dbg.RslamHip(cfg)
+                _, v0, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+                ic = (fr.ic & v0).astype(np.uint8)
+                g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+                g.step_frame(False); g.sync()
+                res.append(g.fetch_results())
+                g.close()
+            finally:
+                os.environ.pop("RSLAM_NO_MACRO", None)
+        a, b = res
+        assert int(a["hi"].sum()) + int(a["li"].sum()) > 100
+        assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
+        assert np.array_equal(a["x_new"], b["x_new"]) and np.array_equal(a["P_new"], b["P_new"])
 
 
 @pytest.mark.parametrize("chi2", [1e-3, 0.05, 0.1, 0.3])
