@@ -15,6 +15,7 @@
 // of rank_update_kernel alone), so Jnorm is simply there when the first block column's quadrants reach their epilogue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "tile_gemm128.h"
 #include "rank_common.h"
@@ -65,64 +66,69 @@ __device__ __forceinline__ void quad_load(const MacroArgs& a, int I, int J, int 
     }
 }
 
+// The epilogue in two halves.  quad_compute: one quadrant's result -- sym(P) [deferred: the materialised P_li] minus the
+// product, K11 applied -- into ITS OWN LDS tile Cs_q[col][row]; nothing is stored to global memory.  quad_store: at the very
+// end, all four tiles out (direct and mirrored).  Why: loads and stores share one counter (vmcnt) and may complete out of
+// order with each other, so a wave that has stores in flight can only wait for a load with vmcnt(0) -- with the stores of
+// quadrant q issued before the loads of quadrant q + 1 were consumed, every quadrant paid a full store acknowledgement plus
+// a load round trip (5.7 us per quadrant, 23 us per tile; a start stagger of the workgroups did not change it: it is not
+// bandwidth).  Now every load of a tile is consumed before its first store is issued.
 template <int QI, bool MAT>
-__device__ __forceinline__ void quad_finish(const MacroArgs& a, const T8Acc& acc, int I, int J, int qj, bool deferred, const QuadIn& in, double* lds)
+__device__ __forceinline__ void quad_compute(const MacroArgs& a, const T8Acc& acc, int I, int J, int qj, bool deferred, const QuadIn& in, double* Cs,
+                                             double* Y1s)
 {
     if (!in.live) return;
     const int bi = 2 * I + QI, bj = 2 * J + qj;
     const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
-    double* Cij = a.Pout + 64L * bi + 64L * bj * a.ldo;
-    double* Cji = a.Pout + 64L * bj + 64L * bi * a.ldo;
     const bool mirror_known = in.mirror_known;
-    double* Cs = lds;
-    double* Ts = lds + TS_DOUBLES;
-    double* Y1s = lds + 2 * TS_DOUBLES;
-    t8_quadrant_to_lds<QI>(acc, qj, Cs, 1.0);
+    double pm[16];
     if (!mirror_known) {
+        // the mirror tile (bj, bi) transposed through this quadrant's own LDS tile (it holds nothing yet)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) Ts[(g + 4 * q) * TS_LD + row] = in.pji[q];
+        for (int q = 0; q < 16; ++q) Cs[(g + 4 * q) * TS_LD + row] = in.pji[q];
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pm[q] = Cs[row * TS_LD + (g + 4 * q)];
+        lds_barrier();
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pm[q] = in.pij[q];
     }
+    t8_quadrant_to_lds<QI>(acc, qj, Cs, 1.0);
     if (MAT && deferred) Y1s[row + 64 * g] = in.y1j;
     lds_barrier();
     double m[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = g + 4 * q;
-        const double pm = mirror_known ? in.pij[q] : Ts[row * TS_LD + c];
-        m[q] = 0.5 * in.pij[q] + 0.5 * pm;
-    }
+    for (int q = 0; q < 16; ++q) m[q] = 0.5 * in.pij[q] + 0.5 * pm[q];
     if (MAT && deferred) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int c = g + 4 * q;
             m[q] -= (in.y1i[0] * Y1s[c] + in.y1i[1] * Y1s[c + 64]) + (in.y1i[2] * Y1s[c + 128] + in.y1i[3] * Y1s[c + 192]);
         }
-        if (bj == 0) {                                 // Jnorm of the low-innovation update on rows / columns 3..6 of M
-            double Tli[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Tli[k] = a.mat.T_li[k];
-            lds_barrier();
-#pragma unroll
-            for (int q = 0; q < 16; ++q) Ts[(g + 4 * q) * TS_LD + row] = m[q];
-            lds_barrier();
-            k11_lds(Ts, Tli, bi);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) m[q] = Ts[(g + 4 * q) * TS_LD + row];
-        }
     }
-    const bool k11 = a.Tq && bj == 0 && a.sel[a.slot_k] != 0;
+    double prod[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = g + 4 * q;
-        const double o = m[q] - Cs[c * TS_LD + row];
-        // (the first block column's tile (bi > 0, 0) has its columns 3..6 rewritten by K11 below: they are stored there, once)
-        if (!(k11 && bi != 0 && c >= 3 && c < 7)) Cij[row + (long)c * a.ldo] = o;
-        Cs[c * TS_LD + row] = o;
+    for (int q = 0; q < 16; ++q) prod[q] = Cs[(g + 4 * q) * TS_LD + row];
+    if (MAT && deferred && bj == 0) {                  // Jnorm of the low-innovation update on rows / columns 3..6 of M
+        double Tli[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Tli[k] = a.mat.T_li[k];
+        lds_barrier();                                 // (the product has been read by everybody)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Cs[(g + 4 * q) * TS_LD + row] = m[q];
+        lds_barrier();
+        k11_lds(Cs, Tli, bi);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m[q] = Cs[(g + 4 * q) * TS_LD + row];
     }
+    lds_barrier();                                     // (the product / M has been read by everybody: the tile takes the result)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Cs[(g + 4 * q) * TS_LD + row] = m[q] - prod[q];
     lds_barrier();
     // K11: the Jnorm congruence of this update on rows / columns 3..6 -- the first block column only (same arithmetic as the
     // 64 x 64 form; Jnorm was written by an earlier launch on this stream)
-    if (k11) {
+    if (a.Tq && bj == 0 && a.sel[a.slot_k] != 0) {
         double T[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) T[k] = a.Tq[k];
@@ -135,7 +141,7 @@ __device__ __forceinline__ void quad_finish(const MacroArgs& a, const T8Acc& acc
                     for (int k = 0; k < 4; ++k) sacc += T[i + 4 * k] * Cs[(3 + k) * TS_LD + j];
                     rb[i] = sacc;
                 }
-                for (int i = 0; i < 4; ++i) { Cs[(3 + i) * TS_LD + j] = rb[i]; Cij[j + (long)(3 + i) * a.ldo] = rb[i]; }
+                for (int i = 0; i < 4; ++i) Cs[(3 + i) * TS_LD + j] = rb[i];
             }
         } else {
             if (j < 64 && !(j >= 3 && j < 7)) {
@@ -163,26 +169,33 @@ __device__ __forceinline__ void quad_finish(const MacroArgs& a, const T8Acc& acc
                 for (int i = 0; i < 4; ++i)
                     for (int c = 0; c < 4; ++c) Cs[(3 + c) * TS_LD + (3 + i)] = out[i][c];
             }
-            // tile (0, 0): every entry may have changed and every thread has stored its own entries above: the second store to
-            // the same address comes from the SAME thread (program order), behind a full barrier for the LDS values
-            __syncthreads();
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const int c = g + 4 * q;
-                Cij[row + (long)c * a.ldo] = Cs[c * TS_LD + row];
-            }
         }
         lds_barrier();
     }
+}
+
+__device__ __forceinline__ void quad_store(const MacroArgs& a, int I, int J, int QI, int qj, const double* Cs)
+{
+    const int bi = 2 * I + QI, bj = 2 * J + qj;
+    if (bj > bi) return;
+    const int row = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double* Cij = a.Pout + 64L * bi + 64L * bj * a.ldo;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int c = g + 4 * q;
+        Cij[row + (long)c * a.ldo] = Cs[c * TS_LD + row];
+    }
     if (bi != bj) {
+        double* Cji = a.Pout + 64L * bj + 64L * bi * a.ldo;
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             const int c = g + 4 * q;
             Cji[row + (long)c * a.ldo] = Cs[row * TS_LD + c];
         }
     }
-    lds_barrier();                                     // Cs / Ts are the next quadrant's
 }
+
+static_assert(T8_LDS_DOUBLES >= 4 * TS_DOUBLES + 256, "the epilogue keeps the four quadrants' results in LDS until all loads are in");
 
 template <bool MAT>
 __global__ void __launch_bounds__(T8_THREADS)
@@ -198,7 +211,7 @@ rank_update_macro_kernel(MacroArgs a)
     T8Src s{{Ya, Ya + 64, Yb, Yb + 64}, a.ldy};
     T8Acc acc;
     t8_zero(acc);
-    // quadrant order (0,0), (1,0), (0,1), (1,1); each one's inputs are requested while the one before is finished
+    // quadrant order (0,0), (1,0), (0,1), (1,1); each one's inputs are requested while the one before is computed
     QuadIn in0, in1;
     quad_load<MAT>(a, I, J, 0, 0, deferred, in0);      // (lands under the K loop)
     tile_gemm128_nt<0, 0>(s, a.K, lds, acc);
@@ -207,13 +220,19 @@ rank_update_macro_kernel(MacroArgs a)
       if (sum == -1.2345) a.Pout[threadIdx.x] = sum + in0.pij[0]; }
     return;
 #endif
+    double* Y1s = lds + 4 * TS_DOUBLES;
     quad_load<MAT>(a, I, J, 1, 0, deferred, in1);
-    quad_finish<0, MAT>(a, acc, I, J, 0, deferred, in0, lds);
+    quad_compute<0, MAT>(a, acc, I, J, 0, deferred, in0, lds, Y1s);
     quad_load<MAT>(a, I, J, 0, 1, deferred, in0);
-    quad_finish<1, MAT>(a, acc, I, J, 0, deferred, in1, lds);
+    quad_compute<1, MAT>(a, acc, I, J, 0, deferred, in1, lds + TS_DOUBLES, Y1s);
     quad_load<MAT>(a, I, J, 1, 1, deferred, in1);
-    quad_finish<0, MAT>(a, acc, I, J, 1, deferred, in0, lds);
-    quad_finish<1, MAT>(a, acc, I, J, 1, deferred, in1, lds);
+    quad_compute<0, MAT>(a, acc, I, J, 1, deferred, in0, lds + 2 * TS_DOUBLES, Y1s);
+    quad_compute<1, MAT>(a, acc, I, J, 1, deferred, in1, lds + 3 * TS_DOUBLES, Y1s);
+    // every load of this tile has been consumed: the stores
+    quad_store(a, I, J, 0, 0, lds);
+    quad_store(a, I, J, 1, 0, lds + TS_DOUBLES);
+    quad_store(a, I, J, 0, 1, lds + 2 * TS_DOUBLES);
+    quad_store(a, I, J, 1, 1, lds + 3 * TS_DOUBLES);
 }
 
 // Tile lists for a map of nT block rows on a device of `cus` compute units.
