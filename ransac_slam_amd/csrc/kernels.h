@@ -51,6 +51,8 @@ struct ScoreTables {          // per matched feature (rank j in feature order), 
     const int32_t* iph;       // state index read as phi
     const int32_t* zsrc;      // feature whose z is compared (Q2 in compat mode)
     const double* sc;         // 4 per matched feature: sin, cos of x[ith], sin, cos of x[iph] at the prior (written by launch_pht)
+    const double* hctx;       // 16 per matched feature: camera pose (7) and rotation (9) of the hypothesis "this feature alone"
+                              // (Tracking.cpp:420-448), written by launch_pht beside the innovation solve
 };
 
 // h_in / has_h_in: previous prediction (nullable); sel_reset: frame scalars to zero (nullable)
@@ -68,7 +70,8 @@ void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int
                 const uint8_t* has_h, double* wv, int32_t* status,
                 const double* x = nullptr, const int32_t* ith = nullptr, const int32_t* iph = nullptr, double* sc = nullptr /* with wv:
                 the angle table of ScoreTables::sc */, const DeferArgs* defer = nullptr /* P is P_li: possibly deferred */,
-                const GateList* gl = nullptr /* with defer: list / count come from the rescue flags (no launch_rescue_gate) */);
+                const GateList* gl = nullptr /* with defer: list / count come from the rescue flags (no launch_rescue_gate) */,
+                double* hctx = nullptr /* with wv: ScoreTables::hctx */);
 
 // The launch-per-step route (systems too large for the persistent sweep) sizes its launch sequence on the host from the
 // frame's own counts.  Besides sel[] the kernel that decides a count writes {count, blocks} and then `seq` into page-locked,

@@ -226,9 +226,27 @@ void launch_predict(hipStream_t s, const Cam& cam, const double* x, const double
 // state of Tracking.cpp:420-422 is then xi = x + (P H_j^T) w_j, the gain K = P H^T S^-1 is
 // never materialised.
 // ---------------------------------------------------------------------------
+// pose (7) and rotation (9, rotcw = q2r(q)^T, column-major) of the state x + c0 w0 + c1 w1 restricted to the camera rows
+__device__ __forceinline__ void hyp_context(const double* __restrict__ x, const double (&c0)[7], const double (&c1)[7], double w0, double w1,
+                                            double* __restrict__ out16)
+{
+    double pose[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) pose[a] = x[a] + (c0[a] * w0 + c1[a] * w1);
+    double Rq[9];
+    q2r(pose + 3, Rq);
+#pragma unroll
+    for (int a = 0; a < 7; ++a) out16[a] = pose[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) out16[7 + a + 3 * b] = Rq[b + 3 * a];
+}
+
 struct InnovArgs {            // all nullable together
     const double* S; const double* z; const double* h; const uint8_t* has_h; double* wv; int32_t* status;
     const double* x; const int32_t* ith; const int32_t* iph; double* sc;      // angle table of the scoring kernel (nullable)
+    double* hctx;             // per matched feature: the hypothesis' camera pose (7) and rotation (9), ScoreTables::hctx (nullable)
 };
 
 template <bool CAN_DEFER>
@@ -280,17 +298,18 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
         sincos(iv.x[iv.ith[c]], &sv, &cv); iv.sc[4 * c] = sv; iv.sc[4 * c + 1] = cv;
         sincos(iv.x[iv.iph[c]], &sv, &cv); iv.sc[4 * c + 2] = sv; iv.sc[4 * c + 3] = cv;
     }
+    double w0 = 0.0, w1 = 0.0;              // (thread 0 of the first row block: the innovation solve of this feature)
     if (iv.wv && blockIdx.x == 0 && threadIdx.x == 0) {
         if (!iv.has_h[f]) {                     // matching() only produces z where h exists (Tracking.cpp:293)
             atomicMin(iv.status, -7);           // RSLAM_ERR_IC_NOT_VISIBLE
-            iv.wv[2 * c] = 0.0; iv.wv[2 * c + 1] = 0.0;
         } else {
             double Si[4] = { iv.S[4 * f], iv.S[4 * f + 1], iv.S[4 * f + 2], iv.S[4 * f + 3] }, Sinv[4];
             inv2_lu(Si, Sinv);
             const double n0 = iv.z[2 * f] - iv.h[2 * f], n1 = iv.z[2 * f + 1] - iv.h[2 * f + 1];
-            iv.wv[2 * c]     = Sinv[0] * n0 + Sinv[2] * n1;
-            iv.wv[2 * c + 1] = Sinv[1] * n0 + Sinv[3] * n1;
+            w0 = Sinv[0] * n0 + Sinv[2] * n1;
+            w1 = Sinv[1] * n0 + Sinv[3] * n1;
         }
+        iv.wv[2 * c] = w0; iv.wv[2 * c + 1] = w1;
     }
     const int o = off[f];
     const double* Hf = H13 + 26 * (long)f;
@@ -352,16 +371,29 @@ pht_kernel(const double* __restrict__ P, int NP, const int32_t* __restrict__ lis
     }
     *reinterpret_cast<d2*>(out + row + (long)(2 * c) * ldo) = a0;
     *reinterpret_cast<d2*>(out + row + (long)(2 * c + 1) * ldo) = a1;
+    // The hypothesis "this feature alone" as the scoring kernel needs it (Tracking.cpp:420-448): camera pose x_i[0:7] = x +
+    // (P H^T) w and its rotation.  Every workgroup of the scoring launch used to rebuild it in all of its lanes -- two
+    // dependent loads and ~180 of its ~350 vector instructions per wave; the rows it needs, 0..6 of this feature's two
+    // columns, are in the registers of lanes 0..3 right here, w in lane 0.
+    if (iv.hctx && blockIdx.x == 0 && threadIdx.x < 64) {
+        double c0[7], c1[7];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            c0[a] = __shfl((a & 1) ? a0.y : a0.x, a >> 1);
+            c1[a] = __shfl((a & 1) ? a1.y : a1.x, a >> 1);
+        }
+        if (threadIdx.x == 0) hyp_context(iv.x, c0, c1, w0, w1, iv.hctx + 16L * c);
+    }
 }
 
 void launch_pht(hipStream_t s, const double* P, int NP, const int32_t* list, int max_count,
                 const int32_t* d_count, const double* H13, const int32_t* off, const uint8_t* type,
                 double* out, long ldo, const double* S, const double* z, const double* h, const uint8_t* has_h,
                 double* wv, int32_t* status, const double* x, const int32_t* ith, const int32_t* iph, double* sc, const DeferArgs* defer,
-                const GateList* gl)
+                const GateList* gl, double* hctx)
 {
     if (max_count <= 0) return;
-    InnovArgs iv{S, z, h, has_h, wv, status, x, ith, iph, sc};
+    InnovArgs iv{S, z, h, has_h, wv, status, x, ith, iph, sc, hctx};
     DeferArgs da{}; if (defer) da = *defer;
     GateList g{}; if (gl && defer) g = *gl;
     const dim3 grid(NP / 512 + (NP % 512 ? 1 : 0), max_count);          // two rows per thread
@@ -384,19 +416,18 @@ struct HypCtx {
 };
 
 __device__ __forceinline__ void hyp_setup(const double* __restrict__ x, const double* __restrict__ W, int NP,
-                                          const double* __restrict__ wv, int p, HypCtx& hc)
+                                          const double* __restrict__ wv, int p, HypCtx& hc, const double* __restrict__ hctx)
 {
     hc.c0 = W + (long)(2 * p) * NP;
     hc.c1 = hc.c0 + NP;
     hc.w0 = wv[2 * p]; hc.w1 = wv[2 * p + 1];
+    // pose and rotation of the hypothesis: tabulated per matched feature by the launch that made its P H^T columns
+    // (pht_kernel, hyp_context: the same expressions on the same values)
+    const double* t = hctx + 16L * p;
 #pragma unroll
-    for (int a = 0; a < 7; ++a) hc.pose[a] = x[a] + (hc.c0[a] * hc.w0 + hc.c1[a] * hc.w1);
-    double Rq[9];
-    q2r(hc.pose + 3, Rq);
+    for (int a = 0; a < 7; ++a) hc.pose[a] = t[a];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) hc.rot[a + 3 * b] = Rq[b + 3 * a];
+    for (int a = 0; a < 9; ++a) hc.rot[a] = t[7 + a];
 }
 
 // squared residual |z_j - h_j(x_i)|^2 of matched feature j under the hypothesis hc (Tracking.cpp:425-476,480-503)
@@ -456,7 +487,7 @@ score_residual_kernel(Cam cam, const double* __restrict__ x, const double* __res
 {
     const int p = blockIdx.x;
     HypCtx hc;
-    hyp_setup(x, W, NP, wv, p, hc);
+    hyp_setup(x, W, NP, wv, p, hc, tab.hctx);
     for (int j = threadIdx.x; j < m; j += blockDim.x) out[(long)p * m + j] = score_residual2(cam, x, hc, tab, z, j);
 }
 
@@ -496,7 +527,7 @@ score_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W
     const int p = pos_list ? pos_list[e] : e;
     if (threadIdx.x == 0) s_count = 0;
     HypCtx hc;
-    hyp_setup(x, W, NP, wv, p, hc);
+    hyp_setup(x, W, NP, wv, p, hc, tab.hctx);
     __syncthreads();
     int local = 0;
     for (int base = 0; base < m; base += blockDim.x) {
@@ -699,7 +730,7 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
         }
     } else if (best >= 0) {
         HypCtx hc;
-        hyp_setup(x, W, NP, wv, sa.pos[best], hc);
+        hyp_setup(x, W, NP, wv, sa.pos[best], hc, tab.hctx);
         for (int base = 0; base < m; base += blockDim.x) {
             const int j = base + threadIdx.x;
             const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);

@@ -82,7 +82,7 @@ struct rslam_ctx {
                     d_sup, d_possup, d_lilist, d_hilist, d_sel;
     DevBuf<uint64_t> d_masks, d_posmask;
     DevBuf<double> d_xpred, d_Ppred, d_h, d_h2, d_H13, d_H13b, d_S, d_S2, d_z, d_wv, d_W, d_A, d_Y, d_Linv,
-                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr, d_sc, d_Y1, d_Gd;
+                   d_x1, d_x2, d_P, d_T, d_probe, d_FQ, d_mapcoef, d_lin, d_patches, d_corr, d_sc, d_hctx, d_Y1, d_Gd;
     DevBuf<uint8_t> d_image;
     DevBuf<double> d_stage;               // drop-in API: the caller's n x n covariance as it crosses PCIe (one linear transfer)
     // feature store: initialisation records of Map::initialize_a_features (Map.cpp:286-292), one slot per feature
@@ -271,7 +271,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
     c->d_sup_local.release(); c->d_sup_all.release(); c->d_macro_order.release(); c->d_small_order.release();
-    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_Y1.release(); c->d_Gd.release();
+    c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_hctx.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     unpin_host_buffers(c);
     staged_release(c);
@@ -462,7 +462,7 @@ static int upload_measurements(rslam_ctx* c, const double* z, const uint8_t* ic,
     ENS(c->d_pos, H); ENS(c->d_nhyp, (size_t)m + 1); ENS(c->d_sup, H); ENS(c->d_possup, m);
     ENS(c->d_masks, (size_t)H * (words ? words : 1)); ENS(c->d_posmask, (size_t)m * (words ? words : 1));
     ENS(c->d_lilist, m); ENS(c->d_hilist, m);
-    ENS(c->d_sc, 4 * (size_t)m); ENS(c->d_wv, 2 * (size_t)m); ENS(c->d_W, (size_t)c->NP * 2 * (m ? m : 1));
+    ENS(c->d_sc, 4 * (size_t)m); ENS(c->d_hctx, 16 * (size_t)(m ? m : 1)); ENS(c->d_wv, 2 * (size_t)m); ENS(c->d_W, (size_t)c->NP * 2 * (m ? m : 1));
     ENS(c->d_A, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Y, (size_t)ldA * (RP ? RP : 1)); ENS(c->d_Linv, (size_t)64 * 64 * (RP / 64 ? RP / 64 : 1));
     if (re) invalidate_graph(c);
 #undef ENS
@@ -490,7 +490,7 @@ static ScoreTables tables(rslam_ctx* c)
 {
     ScoreTables t;
     t.feat = c->d_mfeat.p; t.off = c->d_moff.p; t.type = c->d_mtype.p;
-    t.ith = c->d_mith.p; t.iph = c->d_miph.p; t.zsrc = c->d_mzsrc.p; t.sc = c->d_sc.p;
+    t.ith = c->d_mith.p; t.iph = c->d_miph.p; t.zsrc = c->d_mzsrc.p; t.sc = c->d_sc.p; t.hctx = c->d_hctx.p;
     return t;
 }
 
@@ -516,7 +516,7 @@ static int enqueue_score(rslam_ctx* c, int hb, int he, int32_t* d_sup)
     if (!c->pht_done) {
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
                    c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT,
-                   c->d_xpred.p, c->d_mith.p, c->d_miph.p, c->d_sc.p);
+                   c->d_xpred.p, c->d_mith.p, c->d_miph.p, c->d_sc.p, nullptr, nullptr, c->d_hctx.p);
         c->pht_done = true;
     }
     mark(c, EV_PHT);
@@ -597,7 +597,10 @@ static int enqueue_rank_pass(rslam_ctx* c, hipStream_t x, const double* Pin, dou
     XuArgs plain{};
     plain.mirror_known = mirror_flag;
     plain.token = (slot_k == SEL_K_LI) ? 1 : 2;
-    if (K > 0 && K % 64 == 0 && macro_lists(c)) {
+    // (macro tiles pay from about 20 column blocks on: their epilogue -- four quadrants behind a 128 x 128 x K loop, one
+    //  workgroup per compute unit with nothing to overlap it -- is 25 us per tile whatever K; measured at C5: K = 1600 -20 us,
+    //  K = 1152 + 512 (the two updates of the corrected mode) +22 us against the 64 x 64 form)
+    if (K >= 64 * staged_env_int("RSLAM_MACRO_MIN_BLOCKS", 20) && K % 64 == 0 && macro_lists(c)) {
         if (xu && xu->groups > 0) {
             XuArgs alone = *xu;
             alone.riders_only = 1; alone.Y1out = nullptr; alone.defer_flag = nullptr;
@@ -884,7 +887,7 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     if (!c->pht_done) {   // update without a local score pass (supports came from elsewhere)
         launch_pht(s, c->d_Ppred.p, c->NP, c->d_mfeat.p, c->m, nullptr, c->d_H13.p, c->d_off.p, c->d_type.p,
                    c->d_W.p, c->NP, c->d_S.p, c->d_z.p, c->d_h.p, c->d_hash.p, c->d_wv.p, c->d_sel.p + SEL_STATUS_FRONT,
-                   c->d_xpred.p, c->d_mith.p, c->d_miph.p, c->d_sc.p);
+                   c->d_xpred.p, c->d_mith.p, c->d_miph.p, c->d_sc.p, nullptr, nullptr, c->d_hctx.p);
         c->pht_done = true;
     }
     const bool persistent = sweep_is_persistent(c);

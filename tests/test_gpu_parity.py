@@ -583,6 +583,7 @@ def test_macro_tile_rank_update_equals_64x64_form(hip_dbg):
     posterior must be BIT-identical to the 64 x 64 form's (RSLAM_NO_MACRO in the diagnostic library) -- both arithmetic
     modes at 600 landmarks (57 block rows: an odd count, the last block row goes to the 64 x 64 form as well)."""
     fr = make_frame(L=600, H=100, seed=21)
+    os.environ["RSLAM_MACRO_MIN_BLOCKS"] = "2"              # (the product takes macro tiles from 20 column blocks on)
     for compat in (1, 0):
         cfg = default_config(compat=compat, adaptive=0)
         res = []
@@ -603,6 +604,7 @@ def test_macro_tile_rank_update_equals_64x64_form(hip_dbg):
         assert int(a["hi"].sum()) + int(a["li"].sum()) > 100
         assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
         assert np.array_equal(a["x_new"], b["x_new"]) and np.array_equal(a["P_new"], b["P_new"])
+    os.environ.pop("RSLAM_MACRO_MIN_BLOCKS", None)
 
 
 @pytest.mark.parametrize("chi2", [1e-3, 0.05, 0.1, 0.3])
