@@ -1,5 +1,5 @@
 """A/B of the large-map route inside ONE GPU call (diagnostic library: the switches are read from the environment):
-64 x 64 rank update / macro tiles, launch-per-step sweep / staged route.  ms per frame (eager frames, the large-map route is
+64 x 64 rank update / macro tiles; one-stream sweep / staged route (group solves beside the S stage).  ms per frame (eager frames, the large-map route is
 never graph-captured), the stage times, and every variant's posterior against the first one's.
     python scripts/ab_c5.py [compat] [L]"""
 import os, sys, time
@@ -10,21 +10,20 @@ from ransac_slam_amd.synth import make_frame
 compat = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 fr = make_frame(L=L, H=1000, seed=4)
-variants = [("64x64 tiles, launch-per-step sweep", dict(RSLAM_NO_MACRO="1", RSLAM_NO_STAGED="1")),
-            ("macro tiles,  launch-per-step sweep", dict(RSLAM_NO_STAGED="1")),
-            ("64x64 tiles, staged", dict(RSLAM_NO_MACRO="1")),
-            ("macro tiles,  staged", dict())]
-extra = [a for a in sys.argv[3:] if "=" in a]                  # e.g. RSLAM_STAGED_GROUPS=8,16 applied to the staged variants
+variants = [("64x64 rank update, one-stream sweep", dict(RSLAM_NO_MACRO="1")),
+            ("macro tiles,       one-stream sweep", dict()),
+            ("macro tiles,       staged (group solves)", dict(RSLAM_STAGED_MIN_BLOCKS="12"))]
+SWITCHES = ("RSLAM_NO_MACRO", "RSLAM_STAGED_MIN_BLOCKS")
+extra = [a for a in sys.argv[3:] if "=" in a]                  # e.g. RSLAM_STAGED_CUS_S=64, applied to every variant
 ref = None
 if os.environ.get("AB_ONLY"):                                   # one variant only (under a profiler)
     variants = [variants[int(os.environ["AB_ONLY"])]]
 for name, env in variants:
-    for k in ("RSLAM_NO_MACRO", "RSLAM_NO_STAGED"):
+    for k in SWITCHES:
         os.environ.pop(k, None)
     os.environ.update(env)
-    if "RSLAM_NO_STAGED" not in env:
-        for a in extra:
-            k, v = a.split("=", 1); os.environ[k] = v
+    for a in extra:
+        k, v = a.split("=", 1); os.environ[k] = v
     ctx = api.RslamHip(default_config(compat=compat, adaptive=0), debug=True)
     ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
     ctx.step_predict(); ctx.sync()
