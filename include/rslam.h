@@ -291,6 +291,10 @@ int rslam_update_mode(rslam_ctx* ctx);
 /* The raw device-side code of the last bounded wait that ran out (0: none): which hand-over it was (rslam_sync folds all of
  * them into RSLAM_ERR_HIP or recovers by re-running the update stage, see rslam_get_counters). */
 int rslam_last_raw_status(rslam_ctx* ctx);
+/* Which bounded wait ran out FIRST (0: none since the context was created): code | workgroup << 8 | needed value << 20 with
+ * code = -(raw status) of that wait.  One wait that runs out makes the waits behind it run out too and the status word keeps the
+ * smallest code only; this word names the root.  Diagnosis only. */
+int rslam_last_wait_detail(rslam_ctx* ctx);
 
 /* Block until the stream is idle; returns the device-side status of the
  * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...).

@@ -56,6 +56,7 @@ SYMBOLS = {
     "rslam_get_counters": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "rslam_update_mode": (C.c_int, [C.c_void_p]),
     "rslam_last_raw_status": (C.c_int, [C.c_void_p]),
+    "rslam_last_wait_detail": (C.c_int, [C.c_void_p]),
     "rslam_step_predict": (C.c_int, [C.c_void_p]),
     "rslam_step_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rslam_step_update": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -450,6 +451,11 @@ class RslamHip:
     def last_raw_status(self):
         """raw device-side code of the last bounded wait that ran out (0: none)"""
         return self._L.rslam_last_raw_status(self._h)
+
+    def last_wait_detail(self):
+        """the FIRST bounded wait that ran out: dict(code, workgroup, needed) or None"""
+        v = self._L.rslam_last_wait_detail(self._h)
+        return None if v == 0 else {"code": v & 0xff, "workgroup": (v >> 8) & 0xfff, "needed": (v >> 20) & 0x7ff}
 
     # ---- diagnostics: contexts created with debug=True only (librslam_hip_dbg.so) -------------------------
     def _dbg(self):

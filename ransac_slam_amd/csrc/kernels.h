@@ -13,7 +13,9 @@ namespace rslam {
 enum SelSlot {
     SEL_BEST_HYP = 0, SEL_BEST_SUPPORT = 1, SEL_HYPS_EVALUATED = 2,
     SEL_K_LI = 3, SEL_K_HI = 4, SEL_STATUS = 5, SEL_NBLK_LI = 6, SEL_NBLK_HI = 7, SEL_XU_FLAG = 8,
-    SEL_UNUSED9 = 9,
+    SEL_WAIT_FIRST = 9,      // diagnosis: the FIRST bounded wait of the persistent sweep that ran out since the host last looked
+                             // (code | workgroup << 8 | what it needed << 20; the status word keeps the smallest code only, and one
+                             // wait that runs out makes others run out behind it); kept across the frame reset, cleared by the host
     SEL_STATUS_FRONT = 10,   // status of the prediction / scoring stage (kept when only the update stage is re-run)
     SEL_STICKY = 11,         // smallest status of the frames whose status word the next frame's reset has overwritten unread
     SEL_LI_DEFER = 12,       // != 0: the covariance of the (rank <= 4) low-innovation update has not been written: it is
@@ -109,7 +111,8 @@ void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const doub
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
                       int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init,
                       const uint64_t* masks = nullptr /* every hypothesis' inlier mask of this frame, else the winner is scored again */,
-                      int words = 0, int mask_by_pos = 0, HostCounts host = HostCounts{nullptr, 0});
+                      int words = 0, int mask_by_pos = 0, HostCounts host = HostCounts{nullptr, 0},
+                      const struct LiSmallArgs* li_small = nullptr /* the rank <= 4 low-innovation update inside this launch */);
 
 void launch_rescue_gate(hipStream_t s, int L, const uint8_t* ic, const uint8_t* li, const uint8_t* has_h,
                         const double* S, const double* z, const double* h, double chi2,
@@ -149,6 +152,20 @@ struct SysSrc {
     const int32_t* list; const double* H13; const int32_t* off; const uint8_t* type;
     const double* z; const double* h; const double* Wsrc; const int32_t* rank_of;
 };   // the whole sweep in one launch (no dependence on the previous frame's counts)
+// A low-innovation update of rank <= 4 (the reference-faithful mode: the consensus set is the hypothesis' own feature, Q1) is
+// one 4 x 4 factor and one row solve per state entry; its covariance is deferred (SEL_LI_DEFER).  The consensus launch does it
+// itself right behind the inlier list (li_small_update): Y1, x_k_k, Jnorm, *xu_flag = 1, *defer_flag = 1.  The persistent
+// sweep's low-innovation launch then returns at once (it finds *defer_flag set); the launch-per-step route enqueues nothing.
+struct LiSmallArgs {
+    SysSrc src;                       // list = the consensus launch's own inlier list
+    int NP;
+    const double* x_in; double* x_out; double* Y1; long ldy1; double* T; int compat;
+    int32_t* xu_flag; int32_t* defer_flag; int32_t* status;
+    // must != 0: the launch sequence has NO low-innovation sweep behind this launch (reference-faithful mode: the caller
+    // counts on one or two inliers): any other count is reported as status -40 and the host re-runs the update stage with the
+    // sweep in the sequence.  clear_flags (nullable): the hand-over flag set that sweep would have cleared for the next one.
+    int must; int32_t* clear_flags; int n_clear;
+};
 // returns the buffer (A or Ystore, same shape) whose rows [RP, RP + NP] hold Y and u^T afterwards
 double* launch_factor_sweep(hipStream_t s, const SystemDims& d, const int32_t* sel,
                             int slot_k, int slot_nblk, int host_blocks /* launch-per-step route: the update's block count as the host has read it */, double* A, double* Ystore, double* Linv,

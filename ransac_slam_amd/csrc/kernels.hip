@@ -50,7 +50,7 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
         // sticky slot first: an error of an unchecked frame is reported by the next sync instead of being erased here
         const int old = sel_reset[threadIdx.x];
         const int st = min(__shfl(old, SEL_STATUS, 16), __shfl(old, SEL_STATUS_FRONT, 16));
-        sel_reset[threadIdx.x] = ((int)threadIdx.x == SEL_STICKY) ? min(old, st) : 0;
+        sel_reset[threadIdx.x] = ((int)threadIdx.x == SEL_STICKY) ? min(old, st) : ((int)threadIdx.x == SEL_WAIT_FIRST) ? old : 0;
     }
     const int grp = (threadIdx.x & 63) >> 4;
     const int i = blockIdx.x * 4 + grp;
@@ -700,9 +700,129 @@ __device__ __forceinline__ void host_counts_store(const HostCounts& hc, int coun
     __hip_atomic_store(hc.p + 2, hc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__device__ __forceinline__ void quat_jnorm(double* xq, int compat, double* T);      // (defined with the sweep's x update)
+
+// ---------------------------------------------------------------------------
+// The low-innovation update of rank <= 4 inside the consensus launch (LiSmallArgs).  In the reference-faithful mode the
+// consensus set is the hypothesis' own feature (Q1): the update that follows (ExtendKF.cpp:559-634) is a 2 x 2 (at most 4 x 4)
+// system, one row solve per state entry and the quaternion normalisation -- the covariance part is deferred anyway
+// (SEL_LI_DEFER).  The workgroup that has just written the inlier list does it on the spot: S from the two (four) P H^T
+// columns and the Jacobian rows, the factor in registers, Y1 = (P H^T) L^-T, x_k_k = x + Y1 u, Jnorm -- what the register
+// route of the persistent sweep's strips does (sweep_strip, r_total <= 4) on ~115 workgroups.  This is ONE workgroup: the
+// factor is kept as reciprocals (v_rsq_f64 + two Newton steps: an IEEE division or square root is ~40 instructions, four
+// per row and a dozen per factor made the first version of this 11 us long) and a thread requests all of its rows at once.
+// All threads of the workgroup; blockDim.x a multiple of 64; k = number of inliers (1 or 2).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double li_rsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);              // ~2^-26 relative
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);                       // two Newton steps -> full double
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
+template <bool FOUR>          // two inliers: four columns
+__device__ __forceinline__ void li_small_update_t(const LiSmallArgs& ls, int f0, int j0, int f1, int j1 /* the inliers and their matched-feature indices */)
+{
+    constexpr int r_total = FOUR ? 4 : 2;
+    const int l = threadIdx.x & 63;
+    const SysSrc& src = ls.src;
+    // (column c of P H^T for inlier i is column 2 rank_of[f_i] + (c & 1) of the matched-feature matrix, and rank_of[feat[j]] = j)
+    const double* w0 = src.Wsrc + (long)(2 * j0) * ls.NP;
+    const double* w2 = src.Wsrc + (long)(2 * j1) * ls.NP;
+    const double* wcol[4] = { w0, w0 + ls.NP, w2, w2 + ls.NP };
+    constexpr bool four = FOUR;
+    // the rows of this thread (first round) are requested before anything else: they need no more than the column pointers
+    constexpr int LR = FOUR ? 2 : 4;                                 // rows per thread and round (128 registers per thread: the launch bound is 1024)
+    double q0[LR], q1[LR], q2[LR], q3[LR], xi[LR];
+    auto request = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < LR; ++j) {
+            const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+            const bool ok = i < ls.NP;
+            q0[j] = ok ? wcol[0][i] : 0.0; q1[j] = ok ? wcol[1][i] : 0.0;
+            q2[j] = (ok && four) ? wcol[2][i] : 0.0; q3[j] = (ok && four) ? wcol[3][i] : 0.0;
+            xi[j] = ok ? ls.x_in[i] : 0.0;
+        }
+    };
+    request(0);
+    // the innovation (requested beside the entries of S)
+    double nu4[4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        const int f = c4 < 2 ? f0 : f1;
+        nu4[c4] = c4 < r_total ? src.z[2 * f + (c4 & 1)] - src.h[2 * f + (c4 & 1)] : 0.0;
+    }
+    // S(a, c), lower triangle authoritative: entry e = 4 a + c in lanes 0..15 of every wave (each wave factors for itself)
+    double v;
+    {
+        const int e = l & 15, ea = e >> 2, ec = e & 3;
+        const int a = ea >= ec ? ea : ec, c = ea >= ec ? ec : ea;
+        v = (a == c) ? 1.0 : 0.0;
+        if (a < r_total) {
+            const int fa = a < 2 ? f0 : f1;
+            const int fo = src.off[fa], fw = (src.type[fa] == 0) ? 13 : 10;
+            const double* hf = src.H13 + 26L * fa + 13 * (a & 1);
+            const double* wc = c == 0 ? wcol[0] : c == 1 ? wcol[1] : c == 2 ? wcol[2] : wcol[3];
+            double sacc = 0;
+#pragma unroll
+            for (int q = 0; q < 13; ++q) if (q < fw) sacc += hf[q] * wc[col_index(fo, q)];
+            v += sacc;
+        }
+    }
+    const double s00 = __shfl(v, 0), s10 = __shfl(v, 4), s11 = __shfl(v, 5), s20 = __shfl(v, 8), s21 = __shfl(v, 9),
+                 s22 = __shfl(v, 10), s30 = __shfl(v, 12), s31 = __shfl(v, 13), s32 = __shfl(v, 14), s33 = __shfl(v, 15);
+    // L by columns, its diagonal as reciprocals i_jj = 1 / l_jj
+    const double i00 = li_rsqrt(s00), l10 = s10 * i00, l20 = s20 * i00, l30 = s30 * i00;
+    const double d1 = s11 - l10 * l10, i11 = li_rsqrt(d1), l21 = (s21 - l20 * l10) * i11, l31 = (s31 - l30 * l10) * i11;
+    const double d2v = s22 - l20 * l20 - l21 * l21, i22 = li_rsqrt(d2v), l32 = (s32 - l30 * l20 - l31 * l21) * i22;
+    const double d3 = s33 - l30 * l30 - l31 * l31 - l32 * l32, i33 = li_rsqrt(d3);
+    if (threadIdx.x == 0 && !(s00 > 0.0 && d1 > 0.0 && d2v > 0.0 && d3 > 0.0 && i33 > 1.0e-300)) atomicMin(ls.status, -6);   // RSLAM_ERR_NOT_SPD
+    // u^T = nu^T L^-T
+    const double u0 = nu4[0] * i00, u1 = (nu4[1] - u0 * l10) * i11, u2 = (nu4[2] - u0 * l20 - u1 * l21) * i22,
+                 u3 = (nu4[3] - u0 * l30 - u1 * l31 - u2 * l32) * i33;
+    for (int base = 0; base < ls.NP; base += LR * (int)blockDim.x) {
+        if (base) request(base);
+#pragma unroll
+        for (int j = 0; j < LR; ++j) {
+            const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+            const bool ok = i < ls.NP;                               // (NP is a multiple of 64: uniform per wave)
+            const double x0 = q0[j] * i00, x1 = (q1[j] - x0 * l10) * i11, x2 = (q2[j] - x0 * l20 - x1 * l21) * i22,
+                         x3 = (q3[j] - x0 * l30 - x1 * l31 - x2 * l32) * i33;
+            const double xn = xi[j] + (((x0 * u0 + x1 * u1) + x2 * u2) + x3 * u3);
+            if (ok) {
+                ls.Y1[i] = x0; ls.Y1[i + ls.ldy1] = x1; ls.Y1[i + 2 * ls.ldy1] = x2; ls.Y1[i + 3 * ls.ldy1] = x3;
+            }
+            if (base == 0 && j == 0 && threadIdx.x < 64) {
+                // rows 3..6: quaternion normalisation and Jnorm (ExtendKF.cpp:613-627; Q6)
+                double q[4] = { __shfl(xn, 3), __shfl(xn, 4), __shfl(xn, 5), __shfl(xn, 6) };
+                if (l < 3 || l > 6) ls.x_out[l] = xn;
+                if (l == 0) {
+                    quat_jnorm(q, ls.compat, ls.T);
+                    for (int jj = 0; jj < 4; ++jj) ls.x_out[3 + jj] = q[jj];
+                }
+            } else if (ok) {
+                ls.x_out[i] = xn;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        *ls.xu_flag = 1;            // (token of the low-innovation update; its readers are later launches)
+        *ls.defer_flag = 2;         // P_li = J (sym(P_pred) - Y1 Y1^T) J^T stays implicit (SEL_LI_DEFER; 2: ... and the update is done)
+    }
+}
+
+__device__ void li_small_update(const LiSmallArgs& ls, int k, int f0, int j0, int f1, int j1)
+{
+    if (k > 1) li_small_update_t<true>(ls, f0, j0, f1, j1);
+    else li_small_update_t<false>(ls, f0, j0, f1, j1);
+}
+
 __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
                                const double* __restrict__ wv, const ScoreTables& tab, const double* __restrict__ z, int m,
-                               double thr, const SelectArgs& sa, int* s_wave, int* s_running, int* s_max, int* s_cnt, int* s_rec, int* s_nh)
+                               double thr, const SelectArgs& sa, int* s_wave, int* s_running, int* s_max, int* s_cnt, int* s_rec, int* s_nh,
+                               const LiSmallArgs& ls, bool with_ls /* (no pointer to the by-value kernel argument: it would be copied to scratch) */)
 {
     int32_t* __restrict__ sel = sa.sel;
     uint8_t* __restrict__ li = sa.li;
@@ -726,7 +846,10 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
             if (word < sa.words) bits = mrow[word];
             const bool inl = (j < m) && ((bits >> (j & 63)) & 1ull);
             const int slot = block_compact(inl, s_wave, s_running);
-            if (inl) { const int f = base == 0 ? feat0 : tab.feat[j]; li[f] = 1; list[slot] = f; }
+            if (inl) {
+                const int f = base == 0 ? feat0 : tab.feat[j]; li[f] = 1; list[slot] = f;
+                if (slot < 2) { s_nh[2 * slot] = f; s_nh[2 * slot + 1] = j; }     // (li_small_update: the first two inliers and their columns of W)
+            }
         }
     } else if (best >= 0) {
         HypCtx hc;
@@ -735,7 +858,10 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
             const int j = base + threadIdx.x;
             const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);
             const int slot = block_compact(inl, s_wave, s_running);
-            if (inl) { li[tab.feat[j]] = 1; list[slot] = tab.feat[j]; }
+            if (inl) {
+                li[tab.feat[j]] = 1; list[slot] = tab.feat[j];
+                if (slot < 2) { s_nh[2 * slot] = tab.feat[j]; s_nh[2 * slot + 1] = j; }
+            }
         }
     }
     __syncthreads();
@@ -748,12 +874,33 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
         sel[SEL_K_HI] = 0; sel[SEL_NBLK_HI] = 0;     // written by the second P H^T (GateList); no such launch without matched features
         host_counts_store(sa.host, *s_running, nblk);
     }
+    // a low-innovation update of one or two inliers: here and now (the frame scalars above are out: *defer_flag is written behind them)
+    const int k_li = *s_running;                     // (uniform)
+    if (with_ls) {
+        if (ls.clear_flags) for (int i = threadIdx.x; i < ls.n_clear; i += blockDim.x) ls.clear_flags[i] = 0;
+        if (k_li >= 1 && k_li <= 2) {
+            __syncthreads();
+            li_small_update(ls, k_li, s_nh[0], s_nh[1], s_nh[k_li > 1 ? 2 : 0], s_nh[k_li > 1 ? 3 : 1]);
+        } else if (ls.must && k_li == 0) {
+            // no low-innovation inlier at all (the winner's own feature fell outside the threshold): update() is the identity
+            // (ExtendKF.cpp:635-638).  In the deferred form: Y1 = 0, Jnorm = I -- every reader of P_li forms sym(P_pred), and
+            // the prior is symmetric (exactly when uploaded, to rounding when rslam_ekf_prediction left it)
+            for (int i = threadIdx.x; i < ls.NP; i += blockDim.x) {
+                ls.x_out[i] = ls.x_in[i];
+                ls.Y1[i] = 0.0; ls.Y1[i + ls.ldy1] = 0.0; ls.Y1[i + 2 * ls.ldy1] = 0.0; ls.Y1[i + 3 * ls.ldy1] = 0.0;
+            }
+            if (threadIdx.x < 16) ls.T[threadIdx.x] = ((threadIdx.x & 3) == (threadIdx.x >> 2)) ? 1.0 : 0.0;
+            if (threadIdx.x == 0) { *ls.xu_flag = 1; *ls.defer_flag = 2; }
+        } else if (ls.must && threadIdx.x == 0) {
+            atomicMin(ls.status, -40);              // the sequence was enqueued without the low-innovation sweep this frame needs
+        }
+    }
 }
 
 __global__ void __launch_bounds__(1024)
 best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
                  const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m,
-                 double thr, SelectArgs sa)
+                 double thr, SelectArgs sa, LiSmallArgs ls, int with_li_small)
 {
     __shared__ int s_wave[16];
     __shared__ int s_running;
@@ -761,19 +908,24 @@ best_mask_kernel(Cam cam, const double* __restrict__ x, const double* __restrict
     __shared__ int s_cnt[SEL_MAX_THREADS];
     __shared__ int s_rec[SEL_MAX_RECORDS];
     __shared__ int s_nh[SEL_MAX_THREADS];
-    best_mask_body(cam, x, W, NP, wv, tab, z, m, thr, sa, s_wave, &s_running, s_max, s_cnt, s_rec, s_nh);
+    best_mask_body(cam, x, W, NP, wv, tab, z, m, thr, sa, s_wave, &s_running, s_max, s_cnt, s_rec, s_nh, ls, with_li_small != 0);
 }
 
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
                       int32_t* list, const int32_t* sup, int H, const int32_t* nhyp_table, int adaptive, int n_hyp_init,
-                      const uint64_t* masks, int words, int mask_by_pos, HostCounts host)
+                      const uint64_t* masks, int words, int mask_by_pos, HostCounts host, const LiSmallArgs* li_small)
 {
     int bs = score_block_size(m);
     if (bs < 256) bs = 256;          // the consensus scan wants a few waves even for tiny maps
     const SelectArgs sa{pos, L, sel, li, list, sup, H, nhyp_table, adaptive, n_hyp_init, masks, words, mask_by_pos, host};
-    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, threshold, sa);
+    LiSmallArgs ls{};
+    if (li_small) {
+        ls = *li_small; ls.src.list = list;
+        if (bs < 512) bs = 512;      // (the update's rows: four per thread and round -- C3's 1856 in one)
+    }
+    best_mask_kernel<<<dim3(1), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, threshold, sa, ls, li_small ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1976,11 +2128,19 @@ static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag blo
 // of the chain (~15 us) -- the budget is ~70 times that, so that a launch whose workgroups are not all resident (another user
 // of the device) costs about one frame before the host falls back to the launch-per-step route, not the ~30 ms (140 frames)
 // of the spin-count bound that stood here until round 3.
+// ... AND in polls the wave itself has made (round 5): the wall clock keeps running while the waves of the launch are off the
+// device -- the driver evicts a process's queues for milliseconds at a time when somebody else on the host maps or moves
+// memory -- and when they come back every wait in progress finds its millisecond gone at once.  The round-5 soaks saw one
+// expiry per ~100 000 frames that fits nothing else (profiles/r05_soak.txt: status -37; SEL_WAIT_FIRST: a tile worker's wait
+// for the Y blocks of step 1 ran out FIRST, although the strips that publish them wait for the chain with bounds of their own
+// that started earlier).  A poll is a round trip to the L2 (>= 0.5 us): 768 of them are most of a millisecond of a wave that
+// is RUNNING, which is what the bound is about.
 constexpr unsigned long long SW_WAIT_TICKS = 100ull * 1000;          // 1 ms
+constexpr int SW_WAIT_MIN_POLLS = 768;
 struct SwDeadline {
     unsigned long long t0; int n;
     __device__ __forceinline__ SwDeadline() : t0(wall_clock64()), n(0) {}
-    __device__ __forceinline__ bool expired() { return ((++n & 7) == 0) && (wall_clock64() - t0 > SW_WAIT_TICKS); }
+    __device__ __forceinline__ bool expired() { return ((++n & 7) == 0) && n >= SW_WAIT_MIN_POLLS && (wall_clock64() - t0 > SW_WAIT_TICKS); }
 };
 
 // data that crosses workgroups inside the launch (see "Memory protocol" above)
@@ -1988,6 +2148,13 @@ __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_
 __device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_flag(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// a bounded wait ran out: the status word (smallest code wins) and, for diagnosis, who was first (SEL_WAIT_FIRST; `status` is
+// &sel[SEL_STATUS] in every launch of the persistent sweep)
+__device__ __forceinline__ void sw_timed_out(int32_t* status, int value, int need)
+{
+    atomicMin(status, value);
+    atomicCAS(status + (SEL_WAIT_FIRST - SEL_STATUS), 0, (-value & 0xff) | ((int)(blockIdx.x & 0xfff) << 8) | ((need & 0x7ff) << 20));
+}
 
 // All threads of the workgroup.  Returns true when *flag >= need; false when the spin bound was hit (status -3) or an
 // earlier wait of this workgroup had failed (*abort, in LDS): the caller then leaves at once, so that a broken
@@ -2008,7 +2175,7 @@ __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* 
             __builtin_amdgcn_s_sleep(4);
             a = ld_flag(flag);
             if (b >= need) break;
-            if (dl.expired()) { atomicMin(status, -(30 + code)); *abort = 1; break; }
+            if (dl.expired()) { sw_timed_out(status, -(30 + code), need); *abort = 1; break; }
         }
     }
     __syncthreads();
@@ -2024,7 +2191,7 @@ __device__ __forceinline__ bool sw_wait2(const int32_t* fa, int na, const int32_
         while (true) {
             const int a = ld_flag(fa), b = ld_flag(fb);
             if (a >= na && b >= nb) break;
-            if (dl.expired()) { atomicMin(status, -(30 + code)); *abort = 1; break; }
+            if (dl.expired()) { sw_timed_out(status, -(30 + code), 64 * na + nb); *abort = 1; break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -3253,7 +3420,7 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             if ((t & 63) == 0) __hip_atomic_store(&fl->linv_ready, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (stamp && t == 0) stamp[5] = wall_clock64();
-        if (sh.timeout) { if (t == 0) atomicMin(status, sh.timeout == 5 ? -35 : -(36 + 10 * k)); return; }     // hand-over protocol broke (never expected)
+        if (sh.timeout) { if (t == 0) sw_timed_out(status, sh.timeout == 5 ? -35 : -(36 + 10 * k), k); return; }     // hand-over protocol broke (never expected)
     }
     if (bad) atomicMin(status, -6);                       // RSLAM_ERR_NOT_SPD
 }
@@ -3619,7 +3786,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
             while (true) {
                 const int v = my_flag >= 0 ? ld_flag(&fl->y_flag[my_flag]) : k + 1;
                 if (__all(v >= k + 1)) break;
-                if (dl.expired()) { if (t == 0) { atomicMin(status, -37); *abort = 1; } break; }
+                if (dl.expired()) { if (t == 0) { sw_timed_out(status, -37, k + 1); *abort = 1; } break; }
                 __builtin_amdgcn_s_sleep(4);
             }
         }
@@ -3650,7 +3817,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
                 // Jnorm comes from the strip of state rows 0..15 of this launch (xacc_finish), long ago
                 SwDeadline dl;
                 while (ld_flag(wk.xu_flag) < wk.token) {
-                    if (dl.expired()) { atomicMin(status, -38); break; }
+                    if (dl.expired()) { sw_timed_out(status, -38, 0); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 double T[16];
@@ -3698,6 +3865,8 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
     if (blockIdx.x == 0 && threadIdx.x < SWEEP_FLAG_INTS) flags_other[threadIdx.x] = 0;
     SweepFlags* fl = reinterpret_cast<SweepFlags*>(flags);
     const bool fused = wk.Pout != nullptr;
+    // (the consensus launch has done this low-innovation update itself: li_small_update -- nothing is left for this launch)
+    if (fused && wk.token == 1 && wk.defer_flag && *wk.defer_flag == 2) return;
     int nblk = sel[slot_nblk];
     if (nblk > rp_blocks) nblk = rp_blocks;
     if (nblk <= 0) {                                          // no inliers: update() is the identity (ExtendKF.cpp:635-638)

@@ -94,7 +94,7 @@ struct rslam_ctx {
     bool patches_valid = false;           // d_patches holds the output of rslam_predict_patches for the current prediction
     DevBuf<int32_t> d_first;
     DevBuf<int32_t> d_sup_local, d_sup_all;   // rslam_shard_frame: this rank's slice of the supports, the gathered list
-    DevBuf<int32_t> d_sweep_flags;        // hand-over flags of the persistent factor sweep (zeroed by prepare_system_kernel)
+    DevBuf<int32_t> d_sweep_flags;        // hand-over flags of the persistent factor sweep (zeroed by the sweeps themselves, set by set)
     // timing
     int timing = 0;
     hipEvent_t ev[EV_COUNT];
@@ -112,6 +112,13 @@ struct rslam_ctx {
     const int32_t* last_sup = nullptr;
     int graph_captures = 0;
     int last_raw_status = 0;
+    int last_wait_first = 0;              // SEL_WAIT_FIRST of the last bounded wait that ran out (diagnosis)
+    // Reference-faithful mode: the consensus set is the hypothesis' own feature (Q1) -- one inlier, two by coincidence -- and the
+    // consensus launch does that low-innovation update itself (kernels.h LiSmallArgs): the persistent route's launch sequence
+    // then has NO low-innovation sweep.  A frame with any other count reports -40; rslam_sync re-runs its update stage with
+    // the sweep in the sequence, and the context keeps it there from then on.
+    bool li_skip = false;
+    int li_shape_reruns = 0;
     // The persistent sweep needs its whole grid resident at once.  When a bounded wait runs out (somebody else is holding
     // CUs of this GPU) the update stage is re-run with the launch-per-step sweep, and so are the next frames for a while.
     int steps_frames_left = 0;
@@ -236,6 +243,10 @@ extern "C" int rslam_create(const rslam_config* cfg, int device, rslam_ctx** out
     c->cam.nRows = cfg->cam.nRows; c->cam.nCols = cfg->cam.nCols;
     c->cam.ru2_fast = score_fast_radius2(cfg->cam.k1, cfg->cam.k2, cfg->cam.dx, cfg->cam.dy, cfg->cam.nRows, cfg->cam.nCols);
     c->device = device;
+    c->li_skip = cfg->compat != 0;
+#if defined(RSLAM_DEBUG)
+    if (const char* e = getenv("RSLAM_LI_SKIP")) c->li_skip = atoi(e) != 0;     // tests: the guard of the sequence without a low-innovation sweep
+#endif
     // every failure path below goes through rslam_destroy, which releases whatever exists so far
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->own_stream = nullptr; (void)rslam_destroy(c); return RSLAM_ERR_HIP; }
     c->stream = c->own_stream;
@@ -896,10 +907,27 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     // K5 consensus (Tracking.cpp:507-537)
     // (the winner's inlier mask is the one the scoring launch kept, where this context scored every hypothesis of the frame;
     //  with supports from elsewhere -- other ranks -- the winner is scored again)
+    // A low-innovation update of one or two inliers (compat mode: Q1) is done by the consensus launch itself (kernels.h
+    // LiSmallArgs) wherever its covariance would be deferred: the fused persistent sweep and the launch-per-step route.
+    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
+#if defined(RSLAM_DEBUG)
+    const bool no_defer = getenv("RSLAM_NO_LI_DEFER") != nullptr;       // measurement: the covariance of every LI update is streamed
+    const bool no_li_small = getenv("RSLAM_NO_LI_SMALL") != nullptr;    // measurement / tests: the update as a launch sequence of its own
+#else
+    const bool no_defer = false, no_li_small = false;
+#endif
+    const bool li_small = !no_defer && !no_li_small && c->RP > 0 && c->m > 0 && !(sweep_exp_mask() & (4 | 8 | 512)) /* test switches: the shared route, the in-LDS pipeline, no deferral */ &&
+                          (persistent ? sweep_fused_eligible(d) : true);
+    const bool li_skipped = li_small && persistent && c->li_skip;      // no low-innovation sweep in this frame's sequence
+    const LiSmallArgs ls{SysSrc{c->d_lilist.p, c->d_H13.p, c->d_off.p, c->d_type.p, c->d_z.p, c->d_h.p, c->d_W.p, c->d_rank_of.p},
+                         c->NP, c->d_xpred.p, c->d_x1.p, c->d_Y1.p, c->NP, c->d_T.p, c->cfg.compat,
+                         sel + SEL_XU_FLAG, sel + SEL_LI_DEFER, sel + SEL_STATUS,
+                         li_skipped ? 1 : 0, persistent ? c->d_sweep_flags.p + SWEEP_FLAG_INTS : nullptr, SWEEP_FLAG_INTS};
     launch_best_mask(s, c->cam, c->d_xpred.p, c->d_W.p, c->NP, c->d_wv.p, tables(c), c->d_z.p, c->m, c->d_pos.p,
                      c->cfg.sigma_z, c->L, sel, c->d_li.p, c->d_lilist.p, d_sup, c->H, c->d_nhyp.p,
                      c->cfg.adaptive, c->cfg.n_hyp_init,
-                     c->masks_all == 1 ? c->d_masks.p : c->masks_all == 2 ? c->d_posmask.p : nullptr, c->words, c->masks_all == 2, hc_li);
+                     c->masks_all == 1 ? c->d_masks.p : c->masks_all == 2 ? c->d_posmask.p : nullptr, c->words, c->masks_all == 2, hc_li,
+                     li_small ? &ls : nullptr);
     mark(c, EV_SELECT);
     // Systems too large for the persistent sweep (more 16-row strips than compute units, e.g. 1000 landmarks) run one launch
     // sequence per block step, and how many steps an update needs is only known on the device.  The host reads that one
@@ -916,17 +944,17 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
         }
         blocks_li = cnt[SEL_NBLK_LI - SEL_K_LI];
         // a low-innovation update of rank <= 4 (compat mode: Q1 leaves one or two inliers) does not stream P: kernels.h MatArgs
-#if defined(RSLAM_DEBUG)
-        static const bool no_defer = getenv("RSLAM_NO_LI_DEFER") != nullptr;       // measurement
-#else
-        const bool no_defer = false;
-#endif
         c->li_defer_host = !no_defer && cnt[0] >= 1 && 2 * cnt[0] <= 4 && c->RP > 0;
     }
     // low-innovation update (ExtendKF.cpp:559-596)
-    SystemDims d; d.n = c->n; d.NP = c->NP; d.RP = c->RP; d.ldA = c->ldA;
-    int rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, blocks_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
+    int rc = RSLAM_OK;
+    if (li_skipped || (!persistent && li_small && c->li_defer_host)) {
+        // (done inside the consensus launch: nothing to enqueue)
+        mark(c, EV_LI_FACTOR0); mark(c, EV_LI_FACTOR1); mark(c, EV_LI_RANK0); mark(c, EV_LI_RANK1);
+    } else {
+        rc = enqueue_one_update(c, c->d_lilist.p, SEL_K_LI, SEL_NBLK_LI, blocks_li, c->d_W.p, c->d_H13.p, c->d_h.p, c->d_xpred.p, c->d_x1.p,
                                 c->d_Ppred.p, c->d_P.p, EV_LI_FACTOR0, EV_LI_FACTOR1, EV_LI_RANK0, EV_LI_RANK1);
+    }
     if (rc) return rc;
     mark(c, EV_LI_END);
     // rescue (Tracking.cpp:574-597): re-predict at x_k_k; invisible features keep their stale h
@@ -992,6 +1020,17 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     // resets into SEL_STICKY): reported with this frame, then cleared
     int sticky = sel[SEL_STICKY];
     if (sticky != 0) HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STICKY, 0, sizeof(int32_t), c->stream));
+    if (sel[SEL_WAIT_FIRST] != 0) {
+        c->last_wait_first = sel[SEL_WAIT_FIRST];
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_WAIT_FIRST, 0, sizeof(int32_t), c->stream));
+    }
+    if (sticky == -40) {
+        // an earlier frame of this unsynchronised run needed the low-innovation sweep the sequence did not have (nobody used its
+        // posterior): the sequence gets it back
+        c->li_skip = false;
+        invalidate_graph(c);
+        sticky = 0;
+    }
     if (sticky <= -30 && sticky != -39) {
         // An earlier frame of this unsynchronised run hit a bounded wait of the persistent sweep (somebody else held compute
         // units).  Nobody used its posterior -- every consumer settles the frame in flight first -- so it is not an error of
@@ -1027,7 +1066,25 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     }
     // (codes -31..-38 and the chain's per-block -36-10k: waits of the persistent sweep and its tile workers; -39 is the
     //  rider hand-over of the stand-alone rank update, handled below)
-    const bool sweep_timeout = sel[SEL_STATUS] <= -30 && sel[SEL_STATUS] != -39;
+    if (sel[SEL_STATUS] == -40 && c->last_sup) {
+        // The frame has other than one or two low-innovation inliers and its sequence had no sweep for them (li_skip): re-run
+        // the update stage with the sweep, and keep it in the sequence of this context.
+        if (!c->predicted || !c->have_meas) { c->last_raw_status = -40; c->frame_checked = true; return RSLAM_ERR_HIP; }
+        c->last_raw_status = -40;
+        c->li_skip = false;
+        ++c->li_shape_reruns;
+        invalidate_graph(c);
+        const int timing = c->timing; c->timing = 0;
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream));
+        rc = enqueue_update(c, c->last_sup);
+        c->timing = timing;
+        if (rc) return rc;
+        rc = read_status_raw(c, sel);
+        if (rc) return rc;
+    }
+    const bool sweep_timeout = sel[SEL_STATUS] <= -30 && sel[SEL_STATUS] != -39 && sel[SEL_STATUS] != -40;
     if (sweep_timeout && c->last_sup && sweep_is_persistent(c)) {
         if (!c->predicted || !c->have_meas) {     // the frame's inputs are gone (a new prior was installed unchecked): nothing to re-run from
             c->last_raw_status = sel[SEL_STATUS];
@@ -1564,7 +1621,7 @@ extern "C" int rslam_get_counters(rslam_ctx* c, int32_t* graph_captures, int32_t
 {
     if (!c) return RSLAM_ERR_ARG;
     if (graph_captures) *graph_captures = c->graph_captures;
-    if (sweep_reruns) *sweep_reruns = c->sweep_fallbacks + c->k10_reruns;
+    if (sweep_reruns) *sweep_reruns = c->sweep_fallbacks + c->k10_reruns + c->li_shape_reruns;
     return RSLAM_OK;
 }
 
@@ -1900,6 +1957,7 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
 
 // which bounded wait of the last frame ran out (0: none): the raw device-side code that rslam_sync folds into RSLAM_ERR_HIP
 extern "C" int rslam_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
+extern "C" int rslam_last_wait_detail(rslam_ctx* c) { return c ? c->last_wait_first : 0; }
 // how the update stage of the loaded frame shape runs: 0 launch-per-step sweep + stand-alone rank update, 1 persistent sweep +
 // stand-alone rank update, 2 persistent sweep with the x / covariance update inside its launch
 extern "C" int rslam_update_mode(rslam_ctx* c)

@@ -28,5 +28,5 @@ r1 = ctx.fetch_results(want_P=True)
 ts = np.array(ts)
 same = np.array_equal(r0["x_new"], r1["x_new"]) and np.array_equal(r0["P_new"], r1["P_new"])
 print("L", L, "compat", compat, "frames", frames, "ms/frame median %.4f p99 %.4f max %.4f" % (np.median(ts), np.percentile(ts, 99), ts.max()),
-      "counters", ctx.counters(), "bitwise stable", same, "last raw status", ctx.last_raw_status(),
+      "counters", ctx.counters(), "bitwise stable", same, "last raw status", ctx.last_raw_status(), "first wait", ctx.last_wait_detail(),
       "slow batches (of 100 frames)", [int(i) for i in np.nonzero(ts > 1.2 * np.median(ts))[0][:4]], "of", len(ts))

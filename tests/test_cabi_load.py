@@ -42,7 +42,7 @@ def test_product_library_exports_no_diagnostics(hip_lib):
     # ... and no behaviour switch is read from the environment of a deployed node
     blob = open(build.LIB, "rb").read()
     for env in (b"RSLAM_SWEEP_EXP", b"RSLAM_SWEEP_STEPS", b"RSLAM_GATE_APART", b"RSLAM_NO_LI_DEFER", b"RSLAM_SWEEP_UNFUSED_K10",
-                b"RSLAM_K10_RIDERS_FIRST"):
+                b"RSLAM_K10_RIDERS_FIRST", b"RSLAM_NO_LI_SMALL", b"RSLAM_LI_SKIP", b"RSLAM_NO_MACRO", b"RSLAM_STAGED_MIN_BLOCKS"):
         assert env not in blob, env
 
 

@@ -65,7 +65,7 @@ def test_fused_update_equals_standalone_rank_update(hip_dbg, oracle_lib, compat,
         assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
         assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"]), mask
         Dsym = r1["P_new"] - r1["P_new"].T          # exactly symmetric, except the 4 x 4 block (J P44) J^T, symmetric to
-        assert np.abs(Dsym[3:7, 3:7]).max() <= 1e-15 * np.abs(r1["P_new"][3:7, 3:7]).max()     # rounding as in the reference
+        assert np.abs(Dsym[3:7, 3:7]).max() <= 3e-14 * np.abs(r1["P_new"][3:7, 3:7]).max()     # rounding (an ulp of the block BEFORE the projection)
         Dsym[3:7, 3:7] = 0                                                                   # (ExtendKF.cpp:632)
         assert not Dsym.any()
         assert abs(np.linalg.norm(r1["x_new"][3:7]) - 1.0) < 1e-14
