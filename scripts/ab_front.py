@@ -29,13 +29,14 @@ for name, env in variants:
     ctxs.append((name, ctx, []))
 for k in ("RSLAM_NO_LI_SMALL", "RSLAM_LI_SKIP"):
     os.environ.pop(k, None)
+reps = 2000 if L <= 400 else 100
 for rnd in range(7):
     for name, ctx, ts in ctxs:
         t0 = time.perf_counter()
-        for _ in range(2000):
+        for _ in range(reps):
             ctx.step_frame(True)
         ctx.sync()
-        ts.append((time.perf_counter() - t0) / 2000 * 1e3)
+        ts.append((time.perf_counter() - t0) / reps * 1e3)
 ref = None
 for name, ctx, ts in ctxs:
     r = ctx.fetch_results(want_P=True)

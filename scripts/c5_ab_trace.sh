@@ -14,8 +14,11 @@ python3 - "$f" > "$out/steps_v${v}_c$compat.txt" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-start = max(i for i, r in enumerate(rows) if "predict_kernel<false" in r["Kernel_Name"])
-rows = rows[start:]
+import os
+starts = [i for i, r in enumerate(rows) if "predict_kernel<false" in r["Kernel_Name"]]
+which = int(os.environ.get("TRACE_FRAME", "-1"))          # -1: the last frame (a timed one: events between the stages); e.g. 12: a frame of the untimed back-to-back batches
+start = starts[which]
+rows = rows[start:(starts[which + 1] if which >= 0 and which + 1 < len(starts) else None)]
 t0 = int(rows[0]["Start_Timestamp"])
 queues = {}
 for r in rows:

@@ -647,19 +647,20 @@ def test_li_update_inside_consensus_launch_equals_own_launches(hip_dbg, L, H, se
     assert np.allclose(a["P_new"], b["P_new"], rtol=1e-12, atol=1e-15)
 
 
-def test_sequence_without_li_sweep_is_guarded(hip_dbg, oracle_lib):
+@pytest.mark.parametrize("L,H,seed,frac", [(150, 120, 313, 0.0), (40, 80, 13, 0.2)])
+def test_sequence_without_li_sweep_is_guarded(hip_dbg, oracle_lib, L, H, seed, frac):
     """In the reference-faithful mode the launch sequence of the persistent route has no low-innovation sweep at all: the
     consensus launch does the one- or two-inlier update itself.  The guard: a frame with any other count reports -40, rslam_sync
     re-runs its update stage with the sweep in the sequence and the context keeps it there.  Forced here on the corrected
     arithmetic (RSLAM_LI_SKIP=1 in the diagnostic library), whose consensus sets are large: the first frame must come out
     right after exactly one re-run, the next ones with none."""
-    fr = make_frame(L=150, H=120, seed=313, frac_outlier=0.0)
+    fr = make_frame(L=L, H=H, seed=seed, frac_outlier=frac)
     cfg = default_config(compat=0, adaptive=1)
     o = oracle_lib.Oracle(cfg, structure=1)
     _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
     ic = (fr.ic & v0).astype(np.uint8)
     r0 = o.ransac_update(fr.z, ic, fr.draws)
-    assert int(r0["li"].sum()) > 50
+    assert int(r0["li"].sum()) > 20
     os.environ["RSLAM_LI_SKIP"] = "1"
     try:
         g = hip_dbg.RslamHip(cfg)
@@ -668,6 +669,7 @@ def test_sequence_without_li_sweep_is_guarded(hip_dbg, oracle_lib):
     g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
     g.step_frame(True); g.sync()
     r1 = g.fetch_results()
+    assert g.update_mode() == 2
     assert g.last_raw_status() == -40 and g.counters()["sweep_reruns"] == 1
     assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
     assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
