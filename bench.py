@@ -554,6 +554,10 @@ def main():
         nrep = 30
         acc, outl, med_total = eager_stage_times(ctx, nrep)
         out["stage_us"] = {k: round(v, 2) for k, v in acc.items()}
+        out["stage_note"] = ("eager frames with a hipEvent between the stages (each record costs the stream ~5 us: the sum is well above "
+                             "ms_per_step, which is hipGraph replay without events).  compat = 1: the one- or two-inlier low-innovation "
+                             "update runs INSIDE the consensus launch (select_us) and the sequence has no low-innovation sweep: "
+                             "update_li_us / factor_li_us / rank_update_li_us are then five event records and nothing else")
         out["outliers"] = {"frames_over_3x_median": outl, "median_total_us": round(med_total, 1), "frames": nrep,
                            "note": "eager frames whose total device time exceeded 3x the median, with the stage times of that very frame"}
         n = int(frame.n)

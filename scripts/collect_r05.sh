@@ -28,5 +28,8 @@ echo "c5 ab + traces done"
   echo; echo "== scripts/probes/rocblas_yardstick (vendor library: a yardstick, never linked into the product)"; timeout -k 10 120 scripts/probes/rocblas_yardstick;
   echo; echo "== scripts/probes/gemm128_loop"; timeout -k 10 120 scripts/probes/gemm128_loop; } > "$out/r05_probes.txt" 2>&1 || exit 1
 echo "probes done"
-{ timeout -k 10 500 python scripts/soak.py 1 100000; timeout -k 10 400 python scripts/soak.py 0 50000; timeout -k 10 300 python scripts/soak.py 1 2000 1000 1000 4; timeout -k 10 300 python scripts/soak.py 0 1500 1000 1000 4; } > "$out/r05_soak.txt" 2>&1 || { tail -3 "$out/r05_soak.txt"; exit 1; }
+{ timeout -k 10 300 python scripts/ab_front.py; timeout -k 10 300 python scripts/ab_front.py 1000 1000; } > "$out/r05_front_ab.txt" 2>&1 || { tail -3 "$out/r05_front_ab.txt"; exit 1; }
+echo "front-end ab done"
+{ timeout -k 10 500 python scripts/soak.py 1 100000; timeout -k 10 400 python scripts/soak.py 0 100000; timeout -k 10 400 python scripts/soak.py 0 100000 300 1000 3;
+  timeout -k 10 300 python scripts/soak.py 1 2000 1000 1000 4; timeout -k 10 300 python scripts/soak.py 0 1500 1000 1000 4; } > "$out/r05_soak.txt" 2>&1 || { tail -3 "$out/r05_soak.txt"; exit 1; }
 echo "soak done"
