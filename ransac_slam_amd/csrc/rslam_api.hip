@@ -919,8 +919,9 @@ static int enqueue_update(rslam_ctx* c, const int32_t* d_sup)
     const bool li_small = !no_defer && !no_li_small && c->RP > 0 && c->m > 0 && !(sweep_exp_mask() & (4 | 8 | 512)) /* test switches: the shared route, the in-LDS pipeline, no deferral */ &&
                           (persistent ? sweep_fused_eligible(d) : true);
     // no low-innovation sweep in this frame's sequence (li_skip).  (The launch-per-step route keeps reading the low-innovation
-    // count and simply enqueues nothing for one or two inliers: not waiting for it there -- the host then runs ahead to the
-    // high-innovation count -- measured 13 us per C5 frame SLOWER, scripts/ab_front.py 1000 1000.)
+    // count and simply enqueues nothing for one or two inliers: it has to read the high-innovation count anyway, and not
+    // waiting for this one made no measurable difference at C5, scripts/ab_front.py 1000 1000 -- its frames are the sum of
+    // their kernels either way.)
     const bool li_skipped = li_small && persistent && c->li_skip;
     const LiSmallArgs ls{SysSrc{c->d_lilist.p, c->d_H13.p, c->d_off.p, c->d_type.p, c->d_z.p, c->d_h.p, c->d_W.p, c->d_rank_of.p},
                          c->NP, c->d_xpred.p, c->d_x1.p, c->d_Y1.p, c->NP, c->d_T.p, c->cfg.compat,

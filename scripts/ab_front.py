@@ -13,6 +13,8 @@ fr = make_frame(L=L, H=H, seed=2)
 variants = [("a: sweep launch (strips)          ", dict(RSLAM_NO_LI_SMALL="1", RSLAM_LI_SKIP="0")),
             ("b: consensus launch + empty sweep ", dict(RSLAM_LI_SKIP="0")),
             ("c: consensus launch, no sweep     ", dict(RSLAM_LI_SKIP="1"))]
+if len(sys.argv) > 3:                                            # e.g. "cba": the order the contexts are created (and timed) in --
+    variants = [variants["abc".index(ch)] for ch in sys.argv[3]]  # contexts of one process differ by ~0.5 % at C5 whatever they run
 ctxs = []
 for name, env in variants:
     for k in ("RSLAM_NO_LI_SMALL", "RSLAM_LI_SKIP"):
