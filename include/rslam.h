@@ -279,7 +279,10 @@ int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
  * persistent sweep (or of its tile workers) ran into its bounded wait (its workgroups were not all resident: another user
  * of the GPU), in which case the stage is re-run with the launch-per-step sweep and the context keeps to that sweep for the
  * next 64 frames (doubling while the timeouts keep coming), or because the Jnorm hand-over of the stand-alone rank update
- * timed out (re-run with the x-update riders dispatched first). */
+ * timed out (re-run with the x-update riders dispatched first), or -- compat = 1 contexts, at most once per context -- because
+ * a frame had more than two low-innovation inliers: the launch sequence of that mode has no low-innovation sweep (the
+ * consensus launch does the one- or two-inlier update of ExtendKF.cpp:559-634 itself); the stage is re-run with the sweep and
+ * the context keeps it in the sequence (raw status -40). */
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 /* How the update stage of the loaded frame shape runs: 0 = launch-per-step factor sweep + stand-alone rank update (systems too
  * large for one persistent launch, or the fallback after a timed-out hand-over), 1 = persistent sweep + stand-alone rank
