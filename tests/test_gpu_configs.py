@@ -316,6 +316,43 @@ def test_sequence_of_measurements_on_resident_prior(hip, oracle_lib, compat):
     g.close()
 
 
+def test_compat_frames_with_zero_and_two_li_inliers_at_c3(hip, oracle_lib):
+    """In compat mode the low-innovation consensus set is the winner's own feature -- usually.  Frames 1 and 2 of the
+    benchmark's 32-frame measurement sequence have TWO (a coincidence) and ZERO (the own feature outside the threshold)
+    low-innovation inliers: the consensus launch does the rank-4 update / writes the deferred identity itself, the launch
+    sequence of the mode has no low-innovation sweep, and nothing may be re-run or re-captured."""
+    from ransac_slam_amd.synth import remeasure
+    fr = make_frame(L=300, H=1000, seed=2)
+    cfg = default_config(compat=1, adaptive=0)
+    g = hip.RslamHip(cfg)
+    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    g.step_predict(); g.sync()
+    ic = (fr.ic & g.fetch_prediction()[1]).astype(np.uint8)
+    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+    g.step_frame(True); g.sync()
+    c0 = g.counters()
+    n_frames = 32
+    fracs = [0.05 + 0.5 * abs(((k * 7) % n_frames) / (n_frames - 1) - 0.5) * 2 * 0.9 for k in range(n_frames)]
+    seen = []
+    for k in (1, 2):
+        z, _, draws = remeasure(fr, 100 + k, frac_outlier=fracs[k], H=1000)
+        o = oracle_lib.Oracle(cfg, structure=1)
+        o.predict(fr.types, fr.x_pred, fr.P_pred)
+        r0 = o.ransac_update(z, ic, draws)
+        g.load_measurements(z, ic, draws)
+        g.step_frame(True); g.step_frame(True); g.sync()
+        r1 = g.fetch_results()
+        seen.append(int(r0["li"].sum()))
+        for key in ("best_hyp", "best_support", "hyps_evaluated"):
+            assert r1[key] == r0[key], (k, key)
+        assert np.array_equal(r1["li"], r0["li"]) and np.array_equal(r1["hi"], r0["hi"])
+        assert close_x(r1["x_new"], r0["x_new"]) and close_P(r1["P_new"], r0["P_new"])
+    assert seen == [2, 0]
+    c1 = g.counters()
+    assert c1["graph_captures"] == c0["graph_captures"] and c1["sweep_reruns"] == 0
+    g.close()
+
+
 # --------------------------------------------------------------------------- drop-in API with page-locked caller buffers
 def test_dropin_with_pinned_covariance_buffers(hip):
     """RSLAM_PIN_HOST_COV (rslam_config.reserved bit 0): the caller's p_k_km1 / p_k_k buffers are registered on first use and
