@@ -693,6 +693,20 @@ def test_sequence_without_li_sweep_is_guarded(hip_dbg, oracle_lib, L, H, seed, f
     assert np.array_equal(r3["li"], r0["li"]) and np.array_equal(r3["hi"], r0["hi"])
     assert close_x(r3["x_new"], r0["x_new"]) and close_P(r3["P_new"], r0["P_new"])
     g.close(); g2.close()
+    # ... and a consumer of the posterior in front of any sync: it settles the frame in flight (re-run included) first
+    os.environ["RSLAM_LI_SKIP"] = "1"
+    try:
+        g3 = hip_dbg.RslamHip(cfg)
+    finally:
+        os.environ.pop("RSLAM_LI_SKIP", None)
+    g3.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+    g3.step_frame(True)
+    g3.ekf_prediction(1.0, 0.007, 0.007)
+    xp1, Pp1 = g3.fetch_prior()
+    xp0, Pp0 = oracle_lib.ekf_prediction(r0["x_new"], r0["P_new"], 1.0, 0.007, 0.007)
+    assert close_x(xp1, xp0) and close_P(Pp1, Pp0)
+    assert g3.counters()["sweep_reruns"] == 1
+    g3.close()
 
 
 @pytest.mark.parametrize("chi2", [1e-3, 0.05, 0.1, 0.3])
