@@ -612,14 +612,25 @@ static int enqueue_rank_pass(rslam_ctx* c, hipStream_t x, const double* Pin, dou
     //  workgroup per compute unit with nothing to overlap it -- is 25 us per tile whatever K; measured at C5: K = 1600 -20 us,
     //  K = 1152 + 512 (the two updates of the corrected mode) +22 us against the 64 x 64 form)
     if (K >= 64 * staged_env_int("RSLAM_MACRO_MIN_BLOCKS", 20) && K % 64 == 0 && macro_lists(c)) {
-        if (xu && xu->groups > 0) {
+        // The x update (K9: riders) rides in the 64 x 64 launch of the partial round, which therefore goes FIRST: its ~400 tile
+        // pairs leave a fifth of the device's workgroup slots to the riders, and Jnorm is written when the macro launch's first
+        // block column reaches its epilogue (until round 5's last day the riders were a launch of their own in front: 18 us).
+        const bool riders = xu && xu->groups > 0;
+        const bool ride_small = riders && c->n_small > 0 && staged_env_int("RSLAM_RIDERS_IN_SMALL", 1);
+        if (riders && !ride_small) {
             XuArgs alone = *xu;
             alone.riders_only = 1; alone.Y1out = nullptr; alone.defer_flag = nullptr;
             launch_rank_update(x, c->NP, Pin, c->NP, Ycols, ldy, sel, slot_nblk, K, Pout, c->NP, order, nullptr, slot_k, &alone, nullptr);
         }
+        if (ride_small) {
+            XuArgs with = *xu;
+            with.mirror_known = mirror_flag;
+            launch_rank_update(x, c->NP, Pin, c->NP, Ycols, ldy, sel, slot_nblk, K, Pout, c->NP, c->d_small_order.p, Tq, slot_k, &with, mat,
+                               c->n_small);
+        }
         launch_rank_update_macro(x, Pin, c->NP, Ycols, ldy, K, Pout, c->NP, c->d_macro_order.p, c->n_macro, sel, slot_k, Tq,
                                  mirror_flag, plain.token, mat);
-        if (c->n_small > 0)
+        if (c->n_small > 0 && !ride_small)
             launch_rank_update(x, c->NP, Pin, c->NP, Ycols, ldy, sel, slot_nblk, K, Pout, c->NP, c->d_small_order.p, Tq, slot_k, &plain, mat,
                                c->n_small);
     } else {

@@ -12,8 +12,11 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 fr = make_frame(L=L, H=1000, seed=4)
 variants = [("64x64 rank update, one-stream sweep", dict(RSLAM_NO_MACRO="1")),
             ("macro tiles,       one-stream sweep", dict()),
-            ("macro tiles,       staged (group solves)", dict(RSLAM_STAGED_MIN_BLOCKS="12"))]
-SWITCHES = ("RSLAM_NO_MACRO", "RSLAM_STAGED_MIN_BLOCKS")
+            ("macro tiles,       staged (group solves)", dict(RSLAM_STAGED_MIN_BLOCKS="12")),
+            ("macro tiles, x update as a launch of its own", dict(RSLAM_RIDERS_IN_SMALL="0"))]
+SWITCHES = ("RSLAM_NO_MACRO", "RSLAM_STAGED_MIN_BLOCKS", "RSLAM_RIDERS_IN_SMALL")
+if os.environ.get("AB_SKIP_STAGED"):
+    variants = [v for v in variants if "staged" not in v[0]]
 extra = [a for a in sys.argv[3:] if "=" in a]                  # e.g. RSLAM_STAGED_CUS_S=64, applied to every variant
 ref = None
 if os.environ.get("AB_ONLY"):                                   # one variant only (under a profiler)
