@@ -2131,7 +2131,7 @@ static_assert(sizeof(SweepFlags) == sizeof(int32_t) * SWEEP_FLAG_INTS, "flag blo
 // ... AND in polls the wave itself has made (round 5): the wall clock keeps running while the waves of the launch are off the
 // device -- the driver evicts a process's queues for milliseconds at a time when somebody else on the host maps or moves
 // memory -- and when they come back every wait in progress finds its millisecond gone at once.  The round-5 soaks saw one
-// expiry per ~100 000 frames that fits nothing else (profiles/r05_soak.txt: status -37; SEL_WAIT_FIRST: a tile worker's wait
+// expiry per ~100 000 frames that fits nothing else (NOTEBOOK.md, round 5: status -37; SEL_WAIT_FIRST: a tile worker's wait
 // for the Y blocks of step 1 ran out FIRST, although the strips that publish them wait for the chain with bounds of their own
 // that started earlier).  A poll is a round trip to the L2 (>= 0.5 us): 768 of them are most of a millisecond of a wave that
 // is RUNNING, which is what the bound is about.

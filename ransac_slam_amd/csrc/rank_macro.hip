@@ -11,8 +11,8 @@
 // One workgroup per compute unit (144 KiB of LDS) and 52 MFLOP per tile at K = 1600 make the LAST round expensive (1128
 // macro tiles on 256 compute units: the fifth round would run at 40 % occupancy), so the launch covers whole rounds only and
 // the host hands the remaining tiles to the 64 x 64 form (launch_rank_update_tiles), two workgroups per compute unit.
-// K9 (x_k_k = x + Y u, quaternion, Jnorm) does not ride here: the host runs it as a launch of its own in front (the riders
-// of rank_update_kernel alone), so Jnorm is simply there when the first block column's quadrants reach their epilogue.
+// K9 (x_k_k = x + Y u, quaternion, Jnorm) does not ride here: it rides in the 64 x 64 launch of the partial round, which the
+// host enqueues FIRST (enqueue_rank_pass), so Jnorm is simply there when the first block column's quadrants reach their epilogue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
