@@ -273,6 +273,15 @@ int rslam_step_phase(rslam_ctx* ctx, int32_t phase, int32_t hyp_begin, int32_t h
  * (rslam_load_frame / rslam_load_measurements).  Stream-ordered like rslam_step_frame: results via rslam_sync and
  * rslam_fetch_results. */
 int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph);
+/* The same frame with the exchange as ONE 8-byte all-reduce (north_star: "an RCCL all-reduce ... for the consensus inlier
+ * count"; SURVEY 8e's alternative): each rank folds its slice into key = support << 32 | (0xFFFFFFFF - hypothesis index),
+ * ncclAllReduce(ncclUint64, ncclMax) on the context's stream leaves the LARGEST support and, among equal supports, the
+ * SMALLEST index on every rank -- the earliest strict maximum the loop of Tracking.cpp:507-537 keeps -- and every rank
+ * recomputes the winner's inlier mask itself (one scoring workgroup) before phase 1.  Only for contexts created with
+ * adaptive = 0 (every draw is evaluated; with the adaptive stop of :531-537 the evaluated count depends on the whole list and
+ * the all-gather form is the one to use): RSLAM_ERR_ARG otherwise.  Same results as rslam_shard_frame, bit for bit; same
+ * communicator checks; nccl_comm may be NULL for world == 1. */
+int rslam_shard_frame_allreduce(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph);
 
 /* Diagnostics of the resident pipeline since rslam_create (any pointer may be NULL): hipGraph captures
  * (a change of the launch sequence re-captures); update stages that had to be re-run -- because a hand-over of the
@@ -282,7 +291,9 @@ int rslam_shard_frame(rslam_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
  * timed out (re-run with the x-update riders dispatched first), or -- compat = 1 contexts, at most once per context -- because
  * a frame had more than two low-innovation inliers: the launch sequence of that mode has no low-innovation sweep (the
  * consensus launch does the one- or two-inlier update of ExtendKF.cpp:559-634 itself); the stage is re-run with the sweep and
- * the context keeps it in the sequence (raw status -40). */
+ * the context keeps it in the sequence (raw status -40; the device says so out of band, not as a status value: a frame of
+ * that shape runs its rescue stage and high-innovation pass on a posterior that was never made, and whatever those report
+ * is discarded with it). */
 int rslam_get_counters(rslam_ctx* ctx, int32_t* graph_captures, int32_t* sweep_reruns);
 /* How the update stage of the loaded frame shape runs: 0 = launch-per-step factor sweep + stand-alone rank update (systems too
  * large for one persistent launch, or the fallback after a timed-out hand-over), 1 = persistent sweep + stand-alone rank
@@ -298,6 +309,13 @@ int rslam_last_raw_status(rslam_ctx* ctx);
  * code = -(raw status) of that wait.  One wait that runs out makes the waits behind it run out too and the status word keeps the
  * smallest code only; this word names the root.  Diagnosis only. */
 int rslam_last_wait_detail(rslam_ctx* ctx);
+/* How that wait ran out: (its own polls, saturating at 65535) << 16 | (wall clock it saw go by in microseconds, saturating at
+ * 65535).  A wait on another workgroup of a persistent launch expires only when BOTH bounds are passed: 1 ms of the device's
+ * 100 MHz wall clock AND 768 polls of the waiting wave itself (>= 0.5 us each) -- the wall clock keeps running while the
+ * process's queues are off the device, and a wave that was not running has not waited.  Few polls in a long time therefore
+ * means the waiter was descheduled (the wait does NOT expire: the frame finishes late, with no re-run); >= 768 polls and
+ * >= 1000 us means the hand-over really was withheld.  Diagnosis only. */
+int rslam_last_wait_polls(rslam_ctx* ctx);
 
 /* Block until the stream is idle; returns the device-side status of the
  * frame (RSLAM_OK, RSLAM_ERR_NOT_SPD, RSLAM_ERR_IC_NOT_VISIBLE, ...).

@@ -57,12 +57,14 @@ SYMBOLS = {
     "rslam_update_mode": (C.c_int, [C.c_void_p]),
     "rslam_last_raw_status": (C.c_int, [C.c_void_p]),
     "rslam_last_wait_detail": (C.c_int, [C.c_void_p]),
+    "rslam_last_wait_polls": (C.c_int, [C.c_void_p]),
     "rslam_step_predict": (C.c_int, [C.c_void_p]),
     "rslam_step_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rslam_step_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rslam_step_phase": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "rslam_step_frame": (C.c_int, [C.c_void_p, C.c_int32]),
     "rslam_shard_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "rslam_shard_frame_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "rslam_sync": (C.c_int, [C.c_void_p]),
     "rslam_fetch_prediction": (C.c_int, [C.c_void_p, _dp, _u8p, _dp]),
     "rslam_fetch_results": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, _i32p, _i32p, _i32p, _i32p, _i32p]),
@@ -367,6 +369,11 @@ class RslamHip:
         _chk(self._L.rslam_shard_frame(self._h, C.c_void_p(nccl_comm) if nccl_comm else None, rank, world, 1 if use_graph else 0),
              "rslam_shard_frame")
 
+    def shard_frame_allreduce(self, nccl_comm, rank, world, use_graph=True):
+        """the same frame with ONE 8-byte ncclAllReduce(MAX) of (support << 32 | ~index) instead of the all-gather (adaptive = 0 only)"""
+        _chk(self._L.rslam_shard_frame_allreduce(self._h, C.c_void_p(nccl_comm) if nccl_comm else None, rank, world, 1 if use_graph else 0),
+             "rslam_shard_frame_allreduce")
+
     def sync(self):
         _chk(self._L.rslam_sync(self._h), "rslam_sync")
 
@@ -455,7 +462,11 @@ class RslamHip:
     def last_wait_detail(self):
         """the FIRST bounded wait that ran out: dict(code, workgroup, needed) or None"""
         v = self._L.rslam_last_wait_detail(self._h)
-        return None if v == 0 else {"code": v & 0xff, "workgroup": (v >> 8) & 0xfff, "needed": (v >> 20) & 0x7ff}
+        if v == 0:
+            return None
+        p = self._L.rslam_last_wait_polls(self._h) & 0xffffffff
+        return {"code": v & 0xff, "workgroup": (v >> 8) & 0xfff, "needed": (v >> 20) & 0x7ff,
+                "polls": (p >> 16) & 0xffff, "elapsed_us": p & 0xffff}
 
     # ---- diagnostics: contexts created with debug=True only (librslam_hip_dbg.so) -------------------------
     def _dbg(self):

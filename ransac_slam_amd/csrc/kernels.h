@@ -21,6 +21,13 @@ enum SelSlot {
     SEL_LI_DEFER = 12,       // != 0: the covariance of the (rank <= 4) low-innovation update has not been written: it is
                              // P_li = J (sym(P_pred) - Y1 Y1^T) J^T with Y1 (n x 4) and J (Jnorm of that update) kept aside,
                              // and every reader of P_li until the high-innovation pass has written P forms it on the fly
+    SEL_LI_NEED = 13,        // out of band, not a status code (the status words are min-folded: a code there competes with others):
+                             // bit 0 = THIS frame has other than zero, one or two low-innovation inliers and its launch sequence
+                             // had no low-innovation sweep (rslam_api.hip li_skip); the frame reset turns it into bit 1 = "an
+                             // earlier, unsynchronised frame had"; cleared by the host
+    SEL_WAIT_POLLS = 14,     // diagnosis, written with SEL_WAIT_FIRST by the wait that ran out first: its own polls (16 bits,
+                             // saturating) << 16 | elapsed wall clock in microseconds (16 bits, saturating) -- few polls in a
+                             // long time = the wave was not running (queue eviction), many = the hand-over really was late
     SEL_COUNT = 16
 };
 
@@ -106,6 +113,10 @@ void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos
 
 // K5: consensus replay over the full support list, then re-score the winning hypothesis and
 // scatter its mask to li[], build list/count
+// the consensus exchange as one 8-byte MAX all-reduce (rslam_shard_frame_allreduce): a slice folded into
+// support << 32 | (0xFFFFFFFF - index), and the reduced key expanded into a one-hot support list of H entries
+void launch_shard_key(hipStream_t s, const int32_t* sup_local, int begin, int n, unsigned long long* key);
+void launch_shard_expand(hipStream_t s, const unsigned long long* key, int32_t* sup_all, int H);
 void launch_best_mask(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                       const double* wv, const ScoreTables& tab, const double* z, int m,
                       const int32_t* pos, double threshold, int L, int32_t* sel, uint8_t* li,
@@ -162,8 +173,8 @@ struct LiSmallArgs {
     const double* x_in; double* x_out; double* Y1; long ldy1; double* T; int compat;
     int32_t* xu_flag; int32_t* defer_flag; int32_t* status;
     // must != 0: the launch sequence has NO low-innovation sweep behind this launch (reference-faithful mode: the caller
-    // counts on one or two inliers): any other count is reported as status -40 and the host re-runs the update stage with the
-    // sweep in the sequence.  clear_flags (nullable): the hand-over flag set that sweep would have cleared for the next one.
+    // counts on one or two inliers): any other count is reported out of band (sel[SEL_LI_NEED]; raw code -40 on the host) and
+    // the host re-runs the update stage with the sweep in the sequence.  clear_flags (nullable): the hand-over flag set that sweep would have cleared for the next one.
     int must; int32_t* clear_flags; int n_clear;
 };
 // returns the buffer (A or Ystore, same shape) whose rows [RP, RP + NP] hold Y and u^T afterwards

@@ -50,7 +50,9 @@ predict_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__
         // sticky slot first: an error of an unchecked frame is reported by the next sync instead of being erased here
         const int old = sel_reset[threadIdx.x];
         const int st = min(__shfl(old, SEL_STATUS, 16), __shfl(old, SEL_STATUS_FRONT, 16));
-        sel_reset[threadIdx.x] = ((int)threadIdx.x == SEL_STICKY) ? min(old, st) : ((int)threadIdx.x == SEL_WAIT_FIRST) ? old : 0;
+        sel_reset[threadIdx.x] = ((int)threadIdx.x == SEL_STICKY) ? min(old, st)
+                               : ((int)threadIdx.x == SEL_WAIT_FIRST || (int)threadIdx.x == SEL_WAIT_POLLS) ? old
+                               : ((int)threadIdx.x == SEL_LI_NEED) ? (old ? 2 : 0) : 0;
     }
     const int grp = (threadIdx.x & 63) >> 4;
     const int i = blockIdx.x * 4 + grp;
@@ -579,6 +581,59 @@ void launch_map_support(hipStream_t s, const int32_t* possup, const int32_t* pos
 }
 
 // ---------------------------------------------------------------------------
+// The consensus exchange of the hypothesis-sharded frame as ONE 8-byte MAX all-reduce (north_star's "all-reduce for
+// the consensus inlier count"; rslam_shard_frame_allreduce, adaptive = 0 only): a rank's slice is folded into
+//     key = support << 32 | (0xFFFFFFFF - hypothesis index)
+// so that the maximum over all ranks is the LARGEST support and, among equal supports, the SMALLEST index -- the earliest
+// strict maximum the sequential loop of Tracking.cpp:507-537 keeps (`support > max_hypothesis_support`).  Behind the
+// all-reduce every rank writes the one-hot list {winner: its support, everybody else: 0} and replays the consensus on it as
+// on a gathered list: same winner, same support, and with adaptive = 0 the same evaluated count; the winner's inlier mask is
+// recomputed locally (one scoring workgroup: best_mask_body scores the winner again wherever this context did not score
+// every hypothesis itself).  An empty slice contributes key 0, which loses to every scored hypothesis.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+shard_key_kernel(const int32_t* __restrict__ sup /* this rank's slice: entry 0 = hypothesis `begin` */, int begin, int n,
+                 unsigned long long* __restrict__ key)
+{
+    __shared__ unsigned long long s_k[16];
+    unsigned long long k = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long cand = ((unsigned long long)(unsigned)sup[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(begin + i));
+        k = cand > k ? cand : k;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(k, d);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) k = s_k[w] > k ? s_k[w] : k;
+        *key = k;
+    }
+}
+
+__global__ void shard_expand_kernel(const unsigned long long* __restrict__ key, int32_t* __restrict__ sup_all, int H)
+{
+    const unsigned long long k = *key;
+    const int h = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)), sv = (int)(k >> 32);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H) sup_all[i] = (i == h) ? sv : 0;
+}
+
+void launch_shard_key(hipStream_t s, const int32_t* sup_local, int begin, int n, unsigned long long* key)
+{
+    shard_key_kernel<<<dim3(1), dim3(n > 256 ? 1024 : 256), 0, s>>>(sup_local, begin, n > 0 ? n : 0, key);
+}
+
+void launch_shard_expand(hipStream_t s, const unsigned long long* key, int32_t* sup_all, int H)
+{
+    if (H <= 0) return;
+    shard_expand_kernel<<<dim3((H + 255) / 256), dim3(256), 0, s>>>(key, sup_all, H);
+}
+
+// ---------------------------------------------------------------------------
 // K5: replay of the sequential scan of Tracking.cpp:403,507-537 from the
 // complete support list.  Only strict prefix-maximum records can change the
 // loop state, so the block finds the records in parallel (prefix-max scan) and
@@ -892,7 +947,9 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
             if (threadIdx.x < 16) ls.T[threadIdx.x] = ((threadIdx.x & 3) == (threadIdx.x >> 2)) ? 1.0 : 0.0;
             if (threadIdx.x == 0) { *ls.xu_flag = 1; *ls.defer_flag = 2; }
         } else if (ls.must && threadIdx.x == 0) {
-            atomicMin(ls.status, -40);              // the sequence was enqueued without the low-innovation sweep this frame needs
+            // the sequence was enqueued without the low-innovation sweep this frame needs: said out of band (SEL_LI_NEED), not as
+            // a status code -- whatever the rest of this sequence reports about the posterior it works on is not to outrank it
+            atomicOr(ls.status + (SEL_LI_NEED - SEL_STATUS), 1);
         }
     }
 }
@@ -2141,6 +2198,7 @@ struct SwDeadline {
     unsigned long long t0; int n;
     __device__ __forceinline__ SwDeadline() : t0(wall_clock64()), n(0) {}
     __device__ __forceinline__ bool expired() { return ((++n & 7) == 0) && n >= SW_WAIT_MIN_POLLS && (wall_clock64() - t0 > SW_WAIT_TICKS); }
+    __device__ __forceinline__ unsigned long long elapsed() const { return wall_clock64() - t0; }
 };
 
 // data that crosses workgroups inside the launch (see "Memory protocol" above)
@@ -2150,10 +2208,17 @@ __device__ __forceinline__ int ld_flag(const int32_t* p) { return __hip_atomic_l
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a bounded wait ran out: the status word (smallest code wins) and, for diagnosis, who was first (SEL_WAIT_FIRST; `status` is
 // &sel[SEL_STATUS] in every launch of the persistent sweep)
-__device__ __forceinline__ void sw_timed_out(int32_t* status, int value, int need)
+__device__ __forceinline__ void sw_timed_out(int32_t* status, int value, int need, int polls = 0, unsigned long long ticks = 0)
 {
     atomicMin(status, value);
-    atomicCAS(status + (SEL_WAIT_FIRST - SEL_STATUS), 0, (-value & 0xff) | ((int)(blockIdx.x & 0xfff) << 8) | ((need & 0x7ff) << 20));
+    // (the code field saturates: the chain's per-block codes -(36 + 10 k) leave 8 bits from k = 22 on)
+    const int code = -value > 255 ? 255 : -value;
+    const int first = atomicCAS(status + (SEL_WAIT_FIRST - SEL_STATUS), 0, (code & 0xff) | ((int)(blockIdx.x & 0xfff) << 8) | ((need & 0x7ff) << 20));
+    if (first == 0) {
+        // this wait is the first: how it ran out -- its own polls and the wall clock it saw go by (100 MHz ticks -> us)
+        const unsigned long long us = ticks / 100;
+        status[SEL_WAIT_POLLS - SEL_STATUS] = (int)(((unsigned)(polls > 0xffff ? 0xffff : polls) << 16) | (unsigned)(us > 0xffff ? 0xffff : us));
+    }
 }
 
 // All threads of the workgroup.  Returns true when *flag >= need; false when the spin bound was hit (status -3) or an
@@ -2175,7 +2240,7 @@ __device__ __forceinline__ bool sw_wait(const int32_t* flag, int need, int32_t* 
             __builtin_amdgcn_s_sleep(4);
             a = ld_flag(flag);
             if (b >= need) break;
-            if (dl.expired()) { sw_timed_out(status, -(30 + code), need); *abort = 1; break; }
+            if (dl.expired()) { sw_timed_out(status, -(30 + code), need, dl.n, dl.elapsed()); *abort = 1; break; }
         }
     }
     __syncthreads();
@@ -2191,7 +2256,7 @@ __device__ __forceinline__ bool sw_wait2(const int32_t* fa, int na, const int32_
         while (true) {
             const int a = ld_flag(fa), b = ld_flag(fb);
             if (a >= na && b >= nb) break;
-            if (dl.expired()) { sw_timed_out(status, -(30 + code), 64 * na + nb); *abort = 1; break; }
+            if (dl.expired()) { sw_timed_out(status, -(30 + code), 64 * na + nb, dl.n, dl.elapsed()); *abort = 1; break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -2679,6 +2744,13 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
             } else if (fused) {
                 wait_stores();
                 __syncthreads();
+                if (k == 0 && (exp_mask & 1024) && !is_nu && t == 0) {
+                    // fault injection: a hand-over that is merely LATE -- the first Y block is announced 2 ms of wall clock after
+                    // it was stored, twice the time bound of the waits on it (tests/test_gpu_fused.py: with the waiters
+                    // throttled below SW_WAIT_MIN_POLLS the frame must come out right WITHOUT a re-run)
+                    const unsigned long long t_hold = wall_clock64();
+                    while (wall_clock64() - t_hold < 2ull * SW_WAIT_TICKS) __builtin_amdgcn_s_sleep(64);
+                }
                 if (publish && t == 0) __hip_atomic_store(&fl->y_flag[strip], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else __syncthreads();
             sw_stamp(dbg, who, k, 2);
@@ -3786,8 +3858,10 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
             while (true) {
                 const int v = my_flag >= 0 ? ld_flag(&fl->y_flag[my_flag]) : k + 1;
                 if (__all(v >= k + 1)) break;
-                if (dl.expired()) { if (t == 0) { sw_timed_out(status, -37, k + 1); *abort = 1; } break; }
+                if (dl.expired()) { if (t == 0) { sw_timed_out(status, -37, k + 1, dl.n, dl.elapsed()); *abort = 1; } break; }
                 __builtin_amdgcn_s_sleep(4);
+                // (fault injection: a waiter that hardly runs -- ~7 us per poll, fewer than SW_WAIT_MIN_POLLS in 2 ms)
+                if (exp_mask & 2048) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
             }
         }
         __syncthreads();
@@ -3817,7 +3891,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
                 // Jnorm comes from the strip of state rows 0..15 of this launch (xacc_finish), long ago
                 SwDeadline dl;
                 while (ld_flag(wk.xu_flag) < wk.token) {
-                    if (dl.expired()) { sw_timed_out(status, -38, 0); break; }
+                    if (dl.expired()) { sw_timed_out(status, -38, 0, dl.n, dl.elapsed()); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 double T[16];
@@ -4003,7 +4077,8 @@ static unsigned long long* sweep_dbg_buffer() { return nullptr; }
 // workgroup does not run), bit 5 fault injection (the strips never announce their Y blocks: tile workers and the x update
 // run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep), bit 8 the time
 // stamps of scripts/sweep_stamps.py come from the LI pass instead of the HI pass, bit 9 a low-innovation update of rank <= 4
-// streams P at once instead of deferring its covariance to the high-innovation pass;
+// streams P at once instead of deferring its covariance to the high-innovation pass, bit 10 fault injection (the P H^T strips
+// announce their first Y block 2 ms late), bit 11 fault injection (the tile workers' polls are throttled to ~7 us each);
 // set_sweep_exp_mask overrides the environment (tests)
 #if defined(RSLAM_DEBUG)
 static int g_sweep_exp_override = -1;

@@ -94,6 +94,7 @@ struct rslam_ctx {
     bool patches_valid = false;           // d_patches holds the output of rslam_predict_patches for the current prediction
     DevBuf<int32_t> d_first;
     DevBuf<int32_t> d_sup_local, d_sup_all;   // rslam_shard_frame: this rank's slice of the supports, the gathered list
+    DevBuf<unsigned long long> d_shard_key;   // rslam_shard_frame_allreduce: this rank's key, the reduced key
     DevBuf<int32_t> d_sweep_flags;        // hand-over flags of the persistent factor sweep (zeroed by the sweeps themselves, set by set)
     // timing
     int timing = 0;
@@ -113,10 +114,11 @@ struct rslam_ctx {
     int graph_captures = 0;
     int last_raw_status = 0;
     int last_wait_first = 0;              // SEL_WAIT_FIRST of the last bounded wait that ran out (diagnosis)
+    int last_wait_polls = 0;              // SEL_WAIT_POLLS of the same wait: its polls << 16 | elapsed microseconds
     // Reference-faithful mode: the consensus set is the hypothesis' own feature (Q1) -- one inlier, two by coincidence -- and the
     // consensus launch does that low-innovation update itself (kernels.h LiSmallArgs): the persistent route's launch sequence
-    // then has NO low-innovation sweep.  A frame with any other count reports -40; rslam_sync re-runs its update stage with
-    // the sweep in the sequence, and the context keeps it there from then on.
+    // then has NO low-innovation sweep.  A frame with any other count says so out of band (sel[SEL_LI_NEED]; raw code -40);
+    // rslam_sync re-runs its update stage with the sweep in the sequence, and the context keeps it there from then on.
     bool li_skip = false;
     int li_shape_reruns = 0;
     // The persistent sweep needs its whole grid resident at once.  When a bounded wait runs out (somebody else is holding
@@ -281,7 +283,7 @@ extern "C" int rslam_destroy(rslam_ctx* c)
     c->d_W.release(); c->d_A.release(); c->d_Y.release(); c->d_Linv.release(); c->d_x1.release(); c->d_x2.release();
     c->d_P.release(); c->d_T.release(); c->d_probe.release(); c->d_FQ.release(); c->d_tile_order.release();
     c->d_mapcoef.release(); c->d_lin.release(); c->d_first.release(); c->d_sweep_flags.release();
-    c->d_sup_local.release(); c->d_sup_all.release(); c->d_macro_order.release(); c->d_small_order.release();
+    c->d_sup_local.release(); c->d_sup_all.release(); c->d_shard_key.release(); c->d_macro_order.release(); c->d_small_order.release();
     c->d_patches.release(); c->d_corr.release(); c->d_image.release(); c->d_stage.release(); c->d_sc.release(); c->d_hctx.release(); c->d_Y1.release(); c->d_Gd.release();
     c->d_rec.release(); c->d_rec_patch.release(); c->d_slot.release(); c->d_xyz_src.release(); c->d_pstatus.release();
     unpin_host_buffers(c);
@@ -1037,14 +1039,22 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     if (sticky != 0) HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STICKY, 0, sizeof(int32_t), c->stream));
     if (sel[SEL_WAIT_FIRST] != 0) {
         c->last_wait_first = sel[SEL_WAIT_FIRST];
+        c->last_wait_polls = sel[SEL_WAIT_POLLS];
         HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_WAIT_FIRST, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_WAIT_POLLS, 0, sizeof(int32_t), c->stream));
     }
-    if (sticky == -40) {
-        // an earlier frame of this unsynchronised run needed the low-innovation sweep the sequence did not have (nobody used its
-        // posterior): the sequence gets it back
+    // "this sequence lacked the low-innovation sweep a frame needed" arrives out of band (SEL_LI_NEED: bit 0 this frame, bit 1 an
+    // earlier frame of an unsynchronised run), not as a value competing in the min-folded status words
+    const int li_need = sel[SEL_LI_NEED];
+    if (li_need != 0) HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_LI_NEED, 0, sizeof(int32_t), c->stream));
+    if (li_need & 2) {
+        // an earlier frame of this unsynchronised run needed the sweep (nobody used its posterior): the sequence gets it back.
+        // That frame's rescue stage and high-innovation pass ran on a posterior that was never made: a "not positive definite"
+        // or a timed-out wait they folded into the sticky word says nothing about the data or the device and goes with them;
+        // any other code of the run (an input error of the prediction stage) stays and is reported below as ever.
         c->li_skip = false;
         invalidate_graph(c);
-        sticky = 0;
+        if (sticky == RSLAM_ERR_NOT_SPD || sticky <= -30) sticky = 0;
     }
     if (sticky <= -30 && sticky != -39) {
         // An earlier frame of this unsynchronised run hit a bounded wait of the persistent sweep (somebody else held compute
@@ -1061,6 +1071,26 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
         if (c->rep_status < sel[SEL_STATUS]) sel[SEL_STATUS] = c->rep_status;
         if (c->rep_front < sel[SEL_STATUS_FRONT]) sel[SEL_STATUS_FRONT] = c->rep_front;
         if (c->rep_sticky < sticky) sticky = c->rep_sticky;
+    }
+    if (li_need & 1) {
+        // The frame has other than one or two low-innovation inliers and its sequence had no sweep for them (li_skip): re-run
+        // the update stage with the sweep, and keep it in the sequence of this context.  What the rest of that sequence -- a
+        // rescue stage and a high-innovation pass on a posterior that was never made -- put into the status word goes with it.
+        // (raw code -40, for rslam_last_raw_status: the name this case had when it was a status value)
+        if (!c->last_sup || !c->predicted || !c->have_meas) { c->last_raw_status = -40; c->li_skip = false; invalidate_graph(c); c->frame_checked = true; return RSLAM_ERR_HIP; }
+        c->last_raw_status = -40;
+        c->li_skip = false;
+        ++c->li_shape_reruns;
+        invalidate_graph(c);
+        const int timing = c->timing; c->timing = 0;
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream));
+        rc = enqueue_update(c, c->last_sup);
+        c->timing = timing;
+        if (rc) return rc;
+        rc = read_status_raw(c, sel);
+        if (rc) return rc;
     }
     if (sel[SEL_STATUS] == -39 && c->last_sup && c->predicted && c->have_meas && !c->k10_riders_first) {
         // The first block column of the stand-alone rank update waited for Jnorm in vain: the riders that produce it had been
@@ -1081,25 +1111,7 @@ static int read_status(rslam_ctx* c, int32_t* sel_host)
     }
     // (codes -31..-38 and the chain's per-block -36-10k: waits of the persistent sweep and its tile workers; -39 is the
     //  rider hand-over of the stand-alone rank update, handled below)
-    if (sel[SEL_STATUS] == -40 && c->last_sup) {
-        // The frame has other than one or two low-innovation inliers and its sequence had no sweep for them (li_skip): re-run
-        // the update stage with the sweep, and keep it in the sequence of this context.
-        if (!c->predicted || !c->have_meas) { c->last_raw_status = -40; c->frame_checked = true; return RSLAM_ERR_HIP; }
-        c->last_raw_status = -40;
-        c->li_skip = false;
-        ++c->li_shape_reruns;
-        invalidate_graph(c);
-        const int timing = c->timing; c->timing = 0;
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_STATUS, 0, sizeof(int32_t), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sel.p + SEL_XU_FLAG, 0, sizeof(int32_t), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_sweep_flags.p, 0, sizeof(int32_t) * 2 * SWEEP_FLAG_INTS, c->stream));
-        rc = enqueue_update(c, c->last_sup);
-        c->timing = timing;
-        if (rc) return rc;
-        rc = read_status_raw(c, sel);
-        if (rc) return rc;
-    }
-    const bool sweep_timeout = sel[SEL_STATUS] <= -30 && sel[SEL_STATUS] != -39 && sel[SEL_STATUS] != -40;
+    const bool sweep_timeout = sel[SEL_STATUS] <= -30 && sel[SEL_STATUS] != -39;
     if (sweep_timeout && c->last_sup && sweep_is_persistent(c)) {
         if (!c->predicted || !c->have_meas) {     // the frame's inputs are gone (a new prior was installed unchecked): nothing to re-run from
             c->last_raw_status = sel[SEL_STATUS];
@@ -1739,10 +1751,13 @@ extern "C" int rslam_step_phase(rslam_ctx* c, int32_t phase, int32_t hyp_begin, 
 // ------------------------------------------------------------------------
 namespace {
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, void* /* ncclComm_t */, hipStream_t);
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int /* ncclDataType_t */, int /* ncclRedOp_t */, void* /* ncclComm_t */, hipStream_t);
 typedef int (*nccl_comm_query_fn)(void* /* const ncclComm_t */, int*);
 constexpr int NCCL_INT32 = 2;               // ncclInt32 / ncclInt, rccl.h
+constexpr int NCCL_UINT64 = 5;              // ncclUint64, rccl.h
+constexpr int NCCL_MAX = 2;                 // ncclMax, rccl.h
 
-struct RcclBinding { nccl_allgather_fn allgather; nccl_comm_query_fn count, user_rank; };
+struct RcclBinding { nccl_allgather_fn allgather; nccl_allreduce_fn allreduce; nccl_comm_query_fn count, user_rank; };
 
 const RcclBinding& bind_rccl()
 {
@@ -1760,6 +1775,7 @@ const RcclBinding& bind_rccl()
         };
         RcclBinding r;
         r.allgather = reinterpret_cast<nccl_allgather_fn>(find("ncclAllGather"));
+        r.allreduce = reinterpret_cast<nccl_allreduce_fn>(find("ncclAllReduce"));
         r.count = reinterpret_cast<nccl_comm_query_fn>(find("ncclCommCount"));
         r.user_rank = reinterpret_cast<nccl_comm_query_fn>(find("ncclCommUserRank"));
         return r;
@@ -1768,7 +1784,23 @@ const RcclBinding& bind_rccl()
 }
 }  // namespace
 
+static int shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph, bool by_allreduce);
+
 extern "C" int rslam_shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph)
+{
+    return shard_frame(c, nccl_comm, rank, world, use_graph, false);
+}
+
+// The same frame with north_star's literal collective: ONE ncclAllReduce(MAX) of an 8-byte key instead of the all-gather of the
+// supports (kernels.hip shard_key_kernel).  Only without the adaptive stop (adaptive = 0: every hypothesis is evaluated, so
+// the consensus is the earliest strict maximum and nothing else of the list matters): RSLAM_ERR_ARG otherwise.
+extern "C" int rslam_shard_frame_allreduce(rslam_ctx* c, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph)
+{
+    if (c && c->cfg.adaptive) return RSLAM_ERR_ARG;
+    return shard_frame(c, nccl_comm, rank, world, use_graph, true);
+}
+
+static int shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, int32_t world, int32_t use_graph, bool by_allreduce)
 {
     if (!c || world < 1 || rank < 0 || rank >= world || (!nccl_comm && world > 1)) return RSLAM_ERR_ARG;
     if (!c->have_state || !c->have_meas) return RSLAM_ERR_STATE;
@@ -1784,11 +1816,14 @@ extern "C" int rslam_shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, in
         HIPCHK(hipMemsetAsync(c->d_sup_local.p, 0, sizeof(int32_t) * chunk, c->stream));
         HIPCHK(hipMemsetAsync(c->d_sup_all.p, 0, sizeof(int32_t) * (size_t)chunk * world, c->stream));
     }
+    if (by_allreduce && c->d_shard_key.ensure(2) < 0) return RSLAM_ERR_HIP;
     nccl_allgather_fn allgather = nullptr;
+    nccl_allreduce_fn allreduce = nullptr;
     if (nccl_comm) {
         const RcclBinding& rccl = bind_rccl();
         allgather = rccl.allgather;
-        if (!allgather) return RSLAM_ERR_COMM;
+        allreduce = rccl.allreduce;
+        if (by_allreduce ? !allreduce : !allgather) return RSLAM_ERR_COMM;
         if (c->checked_comm != nccl_comm || c->checked_rank != rank || c->checked_world != world) {
             // a communicator of another size, or this process under another index in it, would leave the all-gather hanging
             // (or scatter the slices wrongly): checked once per (communicator, rank, world), before anything of the frame is
@@ -1803,7 +1838,20 @@ extern "C" int rslam_shard_frame(rslam_ctx* c, void* nccl_comm, int32_t rank, in
     int rc = rslam_step_phase(c, 0, begin, end, c->d_sup_local.p - begin, use_graph);
     if (rc) return rc;
     int32_t* full = c->d_sup_local.p;
-    if (nccl_comm) {
+    if (by_allreduce) {
+        // slice -> key, MAX over the ranks (8 bytes on the wire), key -> one-hot list: the consensus replay of phase 1 then finds
+        // the earliest strict maximum of the WHOLE list, as on the gathered supports (Tracking.cpp:507-537)
+        unsigned long long* key = c->d_shard_key.p;
+        launch_shard_key(c->stream, c->d_sup_local.p, begin, end - begin, key);
+        const unsigned long long* reduced = key;
+        if (nccl_comm) {
+            if (allreduce(key, key + 1, 1, NCCL_UINT64, NCCL_MAX, nccl_comm, c->stream) != 0) return RSLAM_ERR_COMM;
+            reduced = key + 1;
+        }
+        launch_shard_expand(c->stream, reduced, c->d_sup_all.p, H);
+        HIPCHK(hipGetLastError());
+        full = c->d_sup_all.p;
+    } else if (nccl_comm) {
         if (allgather(c->d_sup_local.p, c->d_sup_all.p, (size_t)chunk, NCCL_INT32, nccl_comm, c->stream) != 0) return RSLAM_ERR_COMM;
         full = c->d_sup_all.p;
     }
@@ -1973,6 +2021,7 @@ extern "C" int rslam_k_mfma4_raw(rslam_ctx* c, int32_t cbsz, int32_t abid, const
 // which bounded wait of the last frame ran out (0: none): the raw device-side code that rslam_sync folds into RSLAM_ERR_HIP
 extern "C" int rslam_last_raw_status(rslam_ctx* c) { return c ? c->last_raw_status : 0; }
 extern "C" int rslam_last_wait_detail(rslam_ctx* c) { return c ? c->last_wait_first : 0; }
+extern "C" int rslam_last_wait_polls(rslam_ctx* c) { return c ? c->last_wait_polls : 0; }
 // how the update stage of the loaded frame shape runs: 0 launch-per-step sweep + stand-alone rank update, 1 persistent sweep +
 // stand-alone rank update, 2 persistent sweep with the x / covariance update inside its launch
 extern "C" int rslam_update_mode(rslam_ctx* c)

@@ -86,7 +86,9 @@ public:
     // deletes a feature) re-allocates them: the library drops its registrations whenever the state dimension changes, and
     // map_management code that re-allocates p_k_k / p_k_km1 at an UNCHANGED dimension (a delete followed by an add) calls
     // covariance_buffers_reallocated() first (rslam_unpin_host_buffers)
-    ExtendKF(CamParam* param, int device = 0, int compat = 1, int n_draws = 1400, bool pin_covariance = false)
+    // adaptive: the adaptive stop of the RANSAC loop (Tracking.cpp:531-537); false = every draw is evaluated (benchmarks, and the
+    // one-key all-reduce form of the sharded frame, rslam_shard_frame_allreduce)
+    ExtendKF(CamParam* param, int device = 0, int compat = 1, int n_draws = 1400, bool pin_covariance = false, bool adaptive = true)
         : cam(param), n_draws_(n_draws)
     {
         rslam_config cfg{};
@@ -94,7 +96,7 @@ public:
         cfg.cam.f = param->f; cfg.cam.dx = param->dx; cfg.cam.dy = param->dy;
         cfg.cam.nRows = param->nRows; cfg.cam.nCols = param->nCols;
         cfg.sigma_z = std_z; cfg.p_success = 0.99; cfg.n_hyp_init = 1000; cfg.chi2_gate = 5.9915;
-        cfg.compat = compat; cfg.adaptive = 1; cfg.dedup = 1;
+        cfg.compat = compat; cfg.adaptive = adaptive ? 1 : 0; cfg.dedup = 1;
         cfg.reserved = pin_covariance ? RSLAM_PIN_HOST_COV : 0;
         const int rc = rslam_create(&cfg, device, &ctx_);
         if (rc) throw Error(rc, "rslam_create");

@@ -2,7 +2,9 @@
 // System::TrackRunning (System.cpp:117-129) becomes when the node runs one process per GPU.  Every rank loads the
 // same frame, scores its slice of the draw list, the supports cross the xGMI links in ONE ncclAllGather inside
 // rslam_shard_frame, and every rank ends with the same posterior.
-//   usage: shard_frame_example frame.bin out.bin [rank world idfile [device]]
+//   usage: shard_frame_example frame.bin out.bin [rank world idfile [device [allreduce]]]
+// A seventh argument "allreduce" takes north_star's literal collective instead: the slice's best hypothesis as ONE 8-byte key,
+// ncclAllReduce(MAX) inside rslam_shard_frame_allreduce (no adaptive stop in that form: every draw is evaluated).
 // rank 0 writes the ncclUniqueId to `idfile`, the other ranks wait for it (any shared file system will do; an MPI or
 // ROS launch would broadcast it instead).  With no rank arguments: world = 1, the all-gather runs on a communicator
 // of one rank (what the single-GPU test checks).  Frame / output files as track_frame_example.
@@ -29,6 +31,7 @@ int main(int argc, char** argv)
     const int rank = argc > 3 ? atoi(argv[3]) : 0, world = argc > 4 ? atoi(argv[4]) : 1;
     const char* idfile = argc > 5 ? argv[5] : nullptr;
     const int device = argc > 6 ? atoi(argv[6]) : rank;
+    const bool by_allreduce = argc > 7 && strcmp(argv[7], "allreduce") == 0;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !idfile)) return 2;
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("frame"); return 2; }
@@ -46,7 +49,7 @@ int main(int argc, char** argv)
 
     CamParam cam{0.06333, 0.01390, 240, 320, 1.7945 / 0.0112, 1.4433 / 0.0112, 2.1735, 0.0112, 0.0112};
     try {
-        ExtendKF kf(&cam, device, compat, nd);       // creates the context on this rank's GPU (and selects the device)
+        ExtendKF kf(&cam, device, compat, nd, false, !by_allreduce);       // creates the context on this rank's GPU (and selects the device)
         rslam_ctx* ctx = kf.ctx();
 
         // the communicator of the node: one rank per process / GPU
@@ -81,7 +84,7 @@ int main(int argc, char** argv)
 
         // System.cpp:120-129 on this rank: its slice of the hypotheses, the all-gather, consensus + both updates
         for (int rep = 0; rep < 3; ++rep)           // replays start from the same resident prior (hipGraph from the 2nd on)
-            CHK(rslam_shard_frame(ctx, comm, rank, world, 1));
+            CHK(by_allreduce ? rslam_shard_frame_allreduce(ctx, comm, rank, world, 1) : rslam_shard_frame(ctx, comm, rank, world, 1));
         CHK(rslam_sync(ctx));
 
         std::vector<double> x_new(n), P_new((size_t)n * n);

@@ -8,6 +8,12 @@ gloo in the CPU tests), and every rank replays the sequential consensus scan
 strict maximum + adaptive stop" semantics (Tracking.cpp:403,507-537) survive the
 sharding -- and applies the updates redundantly (no 26 MB covariance broadcast).
 The only collective is that one all-gather of H * 4 bytes.
+
+``mode="allreduce"`` (frames without the adaptive stop, adaptive = 0) replaces it by ONE 8-byte MAX all-reduce: a rank
+folds its slice into ``key = support << 32 | (0xFFFFFFFF - index)``, the maximum over the ranks is the largest support
+and, among equal supports, the smallest index -- the same earliest strict maximum -- and every rank replays the
+consensus on the one-hot list {winner: its support} (the winner's inlier mask is recomputed locally).  The C ABI has the
+same pair: rslam_shard_frame / rslam_shard_frame_allreduce.
 """
 from typing import Protocol, Tuple
 
@@ -34,10 +40,34 @@ class Engine(Protocol):
     def step_update(self, supports_all: torch.Tensor) -> None: ...
 
 
+KEY_INDEX_MASK = 0xFFFFFFFF
+
+
+def slice_key(local: torch.Tensor, begin: int, n: int) -> torch.Tensor:
+    """int64[1]: support << 32 | (0xFFFFFFFF - global index) of the slice's earliest maximum (0 for an empty slice);
+    tensor ops only, so that on a GPU it stays on the stream (no host read-back)."""
+    if n <= 0:
+        return torch.zeros(1, dtype=torch.int64, device=local.device)
+    sup = local[:n].to(torch.int64)
+    idx = torch.arange(begin, begin + n, dtype=torch.int64, device=local.device)
+    return ((sup << 32) | (KEY_INDEX_MASK - idx)).max().reshape(1)
+
+
+def expand_key(key: torch.Tensor, out: torch.Tensor, H: int) -> None:
+    """the one-hot support list of the reduced key: out[winner] = its support, every other entry of out[:H] zero"""
+    out.zero_()
+    if H > 0:
+        h = (KEY_INDEX_MASK - (key & KEY_INDEX_MASK)).clamp_(0, H - 1)
+        out.index_put_((h,), (key >> 32).to(out.dtype))
+
+
 class ShardedFrame:
-    def __init__(self, engine: Engine, group=None):
+    def __init__(self, engine: Engine, group=None, mode: str = "allgather"):
+        if mode not in ("allgather", "allreduce"):
+            raise ValueError("mode is 'allgather' or 'allreduce'")
         self.engine = engine
         self.group = group
+        self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.resize()
@@ -65,7 +95,14 @@ class ShardedFrame:
             e.step_predict()
             e.step_score(self.begin, self.end, self.local)
         full = self.local
-        if self.world > 1:
+        if self.mode == "allreduce":
+            # (adaptive = 0 only: the caller's engine evaluates every hypothesis)
+            key = slice_key(self.local, self.begin, self.end - self.begin)
+            if self.world > 1:
+                dist.all_reduce(key, op=dist.ReduceOp.MAX, group=self.group)
+            expand_key(key, self.all, e.H)
+            full = self.all
+        elif self.world > 1:
             dist.all_gather_into_tensor(self.all, self.local, group=self.group)
             full = self.all
         if hasattr(e, "step_phase"):

@@ -499,8 +499,8 @@ def _properties(fr, ic, r):
     Dsym = P1 - P1.T
     # (Jnorm is a projection along q up to scale: the congruence cancels the prior's quaternion variance (~1.6e-5) down to
     #  entries of 1e-7 .. 1e-11, so the rounding of its 16-term sums is an ulp of the INPUT block, ~3.5e-21 absolute = 3e-14 of the
-    #  output's largest entry; seen: 4e-15 at C3, two congruences in a row)
-    assert np.abs(Dsym[3:7, 3:7]).max() <= 3e-14 * np.abs(P1[3:7, 3:7]).max()
+    #  output's largest entry; seen: 4e-15 at C3, two congruences in a row -- the bound is what was seen with a margin of 2.5)
+    assert np.abs(Dsym[3:7, 3:7]).max() <= 1e-14 * np.abs(P1[3:7, 3:7]).max()
     Dsym[3:7, 3:7] = 0
     assert not Dsym.any()
     assert abs(np.linalg.norm(r["x_new"][3:7]) - 1.0) < 1e-12 or (r["n_li"] + r["n_hi"] == 0)
@@ -589,27 +589,29 @@ def test_macro_tile_rank_update_equals_64x64_form(hip_dbg):
     modes at 600 landmarks (57 block rows: an odd count, the last block row goes to the 64 x 64 form as well)."""
     fr = make_frame(L=600, H=100, seed=21)
     os.environ["RSLAM_MACRO_MIN_BLOCKS"] = "2"              # (the product takes macro tiles from 20 column blocks on)
-    for compat in (1, 0):
-        cfg = default_config(compat=compat, adaptive=0)
-        res = []
-        for no_macro in (False, True):
-            if no_macro:
-                os.environ["RSLAM_NO_MACRO"] = "1"
-            try:
-                g = hip_dbg.RslamHip(cfg)
-                _, v0, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
-                ic = (fr.ic & v0).astype(np.uint8)
-                g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
-                g.step_frame(False); g.sync()
-                res.append(g.fetch_results())
-                g.close()
-            finally:
-                os.environ.pop("RSLAM_NO_MACRO", None)
-        a, b = res
-        assert int(a["hi"].sum()) + int(a["li"].sum()) > 100
-        assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
-        assert np.array_equal(a["x_new"], b["x_new"]) and np.array_equal(a["P_new"], b["P_new"])
-    os.environ.pop("RSLAM_MACRO_MIN_BLOCKS", None)
+    try:                                                    # (a failing assert must not leave the switch set for later tests)
+        for compat in (1, 0):
+            cfg = default_config(compat=compat, adaptive=0)
+            res = []
+            for no_macro in (False, True):
+                if no_macro:
+                    os.environ["RSLAM_NO_MACRO"] = "1"
+                try:
+                    g = hip_dbg.RslamHip(cfg)
+                    _, v0, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+                    ic = (fr.ic & v0).astype(np.uint8)
+                    g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+                    g.step_frame(False); g.sync()
+                    res.append(g.fetch_results())
+                    g.close()
+                finally:
+                    os.environ.pop("RSLAM_NO_MACRO", None)
+            a, b = res
+            assert int(a["hi"].sum()) + int(a["li"].sum()) > 100
+            assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
+            assert np.array_equal(a["x_new"], b["x_new"]) and np.array_equal(a["P_new"], b["P_new"])
+    finally:
+        os.environ.pop("RSLAM_MACRO_MIN_BLOCKS", None)
 
 
 @pytest.mark.parametrize("L,H,seed,compat,n_li", [(300, 1000, 2, 1, 1), (90, 120, 21, 1, 1), (6, 30, 43, 0, 2), (500, 60, 11, 1, None)])

@@ -80,6 +80,67 @@ def test_shard_frame_self_gather():
         c.close()
 
 
+@pytest.mark.parametrize("compat", [1, 0])
+def test_shard_frame_allreduce_self_reduce(oracle_lib, compat):
+    """north_star's literal collective, rslam_shard_frame_allreduce: the slice's best hypothesis as ONE 8-byte key
+    (support << 32 | ~index), ncclAllReduce(ncclUint64, ncclMax) on the context's stream, the winner's mask recomputed locally,
+    then phase 1.  One GPU: no communicator (world 1) and a communicator of one rank (a real self-reduce through RCCL).  The
+    posterior must be the all-gather form's and the whole frame's BIT for bit, the consensus the oracle's earliest strict
+    maximum (Tracking.cpp:507-537; compat = 1 makes nearly every support 0 or 1: ties everywhere), and a context with the
+    adaptive stop must be refused (RSLAM_ERR_ARG): its evaluated count depends on the whole list."""
+    from ransac_slam_amd import api as hip
+    fr = make_frame(L=60, H=257, seed=302)
+    cfg = default_config(compat=compat, adaptive=0)
+    o = oracle_lib.Oracle(cfg, structure=1)
+    _, v0, _ = o.predict(fr.types, fr.x_pred, fr.P_pred)
+    ic = (fr.ic & v0).astype(np.uint8)
+    r0 = o.ransac_update(fr.z, ic, fr.draws)
+    fr.ic = ic
+    full = _reference(hip, fr, cfg)
+    for k in ("best_hyp", "best_support", "hyps_evaluated"):
+        assert full[k] == r0[k], k
+    c = hip.RslamHip(cfg)
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+    for _ in range(2):
+        c.shard_frame_allreduce(None, 0, 1, True)
+    c.sync()
+    part = c.fetch_results()
+    assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+    rccl = _rccl()
+    uid = NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        for use_graph in (False, True, True):
+            c.shard_frame_allreduce(comm.value, 0, 1, use_graph)
+        c.sync()
+        red = c.fetch_results()
+        c.shard_frame(comm.value, 0, 1, True)
+        c.sync()
+        gat = c.fetch_results()
+        for part in (red, gat):
+            for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+                assert part[k] == full[k], k
+            assert np.array_equal(part["li"], r0["li"]) and np.array_equal(part["hi"], r0["hi"])
+            assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+        with pytest.raises(hip.RslamError) as e:
+            c.shard_frame_allreduce(comm.value, 0, 2, True)          # a communicator of another shape: as for the all-gather form
+        assert e.value.code == -8
+        # the adaptive stop and the one-key exchange do not go together
+        ca = hip.RslamHip(default_config(compat=compat, adaptive=1))
+        ca.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+        with pytest.raises(hip.RslamError) as e:
+            ca.shard_frame_allreduce(comm.value, 0, 1, True)
+        assert e.value.code == -1
+        ca.close()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+        c.close()
+
+
 def test_shard_frame_refuses_a_communicator_of_another_shape():
     """A 1-rank communicator offered as rank 0 (or 1) of a world of 2 must come back as RSLAM_ERR_COMM (-8) before anything
     is enqueued -- on a fresh context, and again on a context that has already validated the SAME communicator for
@@ -117,14 +178,15 @@ def test_shard_frame_refuses_a_communicator_of_another_shape():
         fresh.close()
 
 
-@pytest.mark.parametrize("compat", [1, 0])
-def test_cpp_shard_frame_example(oracle_lib, tmp_path, compat):
-    """host/shard_frame_example.cpp (C++, owns the ncclComm_t) as rank 0 of 1, against the oracle."""
+@pytest.mark.parametrize("compat,mode", [(1, "allgather"), (0, "allgather"), (0, "allreduce"), (1, "allreduce")])
+def test_cpp_shard_frame_example(oracle_lib, tmp_path, compat, mode):
+    """host/shard_frame_example.cpp (C++, owns the ncclComm_t) as rank 0 of 1, against the oracle: the all-gather form
+    (adaptive stop replayed on the gathered list) and the one-key all-reduce form (every draw evaluated)."""
     from ransac_slam_amd import build
     build.build()
     exe = build.build_shard_example()
     fr = make_frame(L=60, H=1100, seed=501, frac_ic=0.9)
-    cfg = default_config(compat=compat, adaptive=1)
+    cfg = default_config(compat=compat, adaptive=0 if mode == "allreduce" else 1)
     o = oracle_lib.Oracle(cfg, structure=1)
     h0, v0, S0 = o.predict(fr.types, fr.x_pred, fr.P_pred)
     ic = (fr.ic & v0).astype(np.uint8)
@@ -135,7 +197,8 @@ def test_cpp_shard_frame_example(oracle_lib, tmp_path, compat):
         f.write(fr.types.tobytes()); f.write(fr.ic.astype(np.uint8).tobytes())
         f.write(fr.x_pred.tobytes()); f.write(np.asfortranarray(fr.P_pred).tobytes(order="F"))
         f.write(np.ascontiguousarray(fr.z).tobytes()); f.write(fr.draws.tobytes())
-    subprocess.check_call([exe, str(fin), str(fout)], timeout=300)
+    argv = [exe, str(fin), str(fout)] + (["0", "1", str(tmp_path / "nccl_id"), "0", "allreduce"] if mode == "allreduce" else [])
+    subprocess.check_call(argv, timeout=300)
     raw = open(fout, "rb").read()
     n, L = fr.n, fr.L
     sc = np.frombuffer(raw, np.int32, 3); p = 12
