@@ -3554,6 +3554,45 @@ __device__ __forceinline__ WkTile wk_tile(const WorkerArgs& wk, int ti, int ntil
     return r;
 }
 
+// Which tiles a worker owns.  A workgroup runs on XCD (blockIdx mod 8) and the eight XCDs have an L2 each: with the tiles dealt
+// round-robin over the worker INDEX (the round-3 form: tile widx + j W) every XCD's workers touched every 64-row panel of Y,
+// and each Y block was fetched eight times (58 of the launch's 107 MB of reads at C3).  Now (round 6) XCD x's workers own a
+// contiguous run of the region-major tile sequence (the 8 x 8 regions of make_rank_update_order: ~16 of the 29 panels at C3),
+// sized in proportion to the number of workers the XCD has in THIS launch -- the worker set depends on the inlier count -- and
+// dealt round-robin inside the XCD: tile lo + y + j nx.  Which workgroup computes a tile does not change a bit of it.
+struct WkMap {
+    int widx, W;              // the worker's index and the number of workers (the round-3 form, kept where the run per XCD would not fit)
+    int lo, hi, y, nx;        // XCD form: this XCD's run [lo, hi) of the sequence, the worker's rank among the XCD's nx workers
+    bool by_xcd;
+};
+
+// numbers v in [a, b] with v mod 8 == x (0 for an empty range)
+__device__ __forceinline__ int wk_count_res(int a, int b, int x)
+{
+    if (b < a) return 0;
+    return (b - x + 64) / 8 - (a - 1 - x + 64) / 8;        // (+64: floor division of small negatives)
+}
+
+// entry s of the region-major sequence, recovered from the XCD-interleaved order array (order[8 idx + x] = seq[start(x) + idx],
+// eighths of q or q + 1 entries: make_rank_update_order)
+__device__ __forceinline__ int wk_seq_entry(const int32_t* __restrict__ order, int T, int s)
+{
+    const int q = T / 8, r = T % 8;
+    const int x = (s < r * (q + 1)) ? s / (q + 1) : r + (s - r * (q + 1)) / q;
+    const int start = x * q + (x < r ? x : r);
+    return order[8 * (s - start) + x];
+}
+
+__device__ __forceinline__ WkTile wk_tile_j(const WorkerArgs& wk, const WkMap& m, int j, int ntiles)
+{
+    if (!m.by_xcd) return wk_tile(wk, m.widx + j * m.W, ntiles);
+    WkTile r; r.bi = 0; r.bj = 0;
+    const int sidx = m.lo + m.y + j * m.nx;
+    r.have = sidx < m.hi;
+    if (r.have) { const int e = wk_seq_entry(wk.tile_order, ntiles, sidx); r.bi = e >> 16; r.bj = e & 0xffff; }
+    return r;
+}
+
 // K11 on one tile of the first block column, in its LDS image Cs[col][row] (64 threads, j = row of tile (bi,0) = column of
 // its mirror): the Jnorm congruence on rows / columns 3..6 (ExtendKF.cpp:629-634); same arithmetic as a separate pass over
 // P would do.  For bi != 0 only the tile's columns 3..6 change (its mirror carries the rows).
@@ -3706,10 +3745,11 @@ __device__ __forceinline__ void wk_block(TgAcc (&acc)[WK_SLOTS], const WkTile (&
     });
 }
 
-__device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int r_total, int rp_blocks, long ldA, const double* Ypanel,
+__device__ __forceinline__ void sweep_tile_worker(const WkMap& map, int nblk, int r_total, int rp_blocks, long ldA, const double* Ypanel,
                                                   const WorkerArgs& wk, SweepFlags* fl, const int32_t* __restrict__ sel, int slot_k,
                                                   int32_t* status, double* lds, int* abort, unsigned long long* dbg, int exp_mask)
 {
+    const int widx = map.widx;
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), half = wave >> 2, wave4 = wave & 3;
     const int lane = t & 63;
@@ -3720,8 +3760,8 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
     int n_wg = 0;
 #pragma unroll
     for (int slot = 0; slot < WK_SLOTS; ++slot) {
-        tl[slot] = wk_tile(wk, widx + (2 * slot + half) * W, ntiles);
-        if (widx + 2 * slot * W < ntiles) n_wg = slot + 1;            // (engine 0 has at least as many tiles as engine 1)
+        tl[slot] = wk_tile_j(wk, map, 2 * slot + half, ntiles);
+        if (wk_tile_j(wk, map, 2 * slot, ntiles).have) n_wg = slot + 1;            // (engine 0 has at least as many tiles as engine 1)
     }
     if (n_wg == 0) return;
     const bool timing = dbg && widx == 0;
@@ -3822,7 +3862,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
                             acc[slot][mi][0][q] -= ((yr[0] * yc[q][0] + yr[1] * yc[q][1]) + yr[2] * yc[q][2]) + yr[3] * yc[q][3];
                     }
                 }
-                const WkTile t0 = wk_tile(wk, widx + (2 * slot) * W, ntiles), t1 = wk_tile(wk, widx + (2 * slot + 1) * W, ntiles);
+                const WkTile t0 = wk_tile_j(wk, map, 2 * slot, ntiles), t1 = wk_tile_j(wk, map, 2 * slot + 1, ntiles);
                 if ((t0.have && t0.bj == 0) || (t1.have && t1.bj == 0)) {            // (uniform over the workgroup)
                     const bool fix = mine && tl[slot].bj == 0;
                     __syncthreads();
@@ -3846,7 +3886,7 @@ __device__ __forceinline__ void sweep_tile_worker(int widx, int W, int nblk, int
     int my_flag = -1;
     if (t < 8 * WK_TILES) {
         const int s6 = t >> 3, sub = t & 7;                          // tile s6 = 2 slot + engine
-        const WkTile tt = wk_tile(wk, widx + s6 * W, ntiles);
+        const WkTile tt = wk_tile_j(wk, map, s6, ntiles);
         if (tt.have) my_flag = 4 * rp_blocks + 4 * (sub < 4 ? tt.bi : tt.bj) + (sub & 3);
     }
     const double* Y = Ypanel + RP;
@@ -3984,8 +4024,32 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
         // afterwards (the covariance pass is then a stream over P shared by every compute unit of the device).
         const int n_late = single ? NP / 16 + 1 : 0;
         const int n_workers = extra + n_idle_s + 3 + n_late;
+        // The XCD-aware tile map (WkMap): the workers are the workgroups of up to five runs of block indices -- the strips of
+        // S row blocks 0, 1; of the padding row blocks; the three strips below nu^T; the blocks behind the strips; and, for a
+        // system of one diagonal block, the P H^T / nu strips that join late -- so a worker's rank inside its XCD and every
+        // XCD's worker count are sums of residue counts over those runs.
+        auto make_map = [&](int my_bx, int my_widx) {
+            WkMap m; m.widx = my_widx; m.W = n_workers; m.lo = m.hi = m.y = 0; m.nx = 1; m.by_xcd = false;
+            const int T = wk.nT * (wk.nT + 1) / 2;
+            if (!wk.tile_order || T < 64 || (exp_mask & 4096)) return m;       // (bit 12: the round-3 assignment, for A/B measurements)
+            const int ra[5] = {1, 4 * hi0 + 1, nstrips - 2, nstrips + 1, 4 * rp_blocks + 1};
+            const int rb[5] = {4 * lo_blocks, 4 * rp_blocks, nstrips, (int)gridDim.x - 1, single ? 4 * rp_blocks + NP / 16 + 1 : 0};
+            const int x = my_bx & 7;
+            int before = 0, nx = 0, y = 0;
+            for (int k = 0; k < 5; ++k) {
+                for (int xx = 0; xx < x; ++xx) before += wk_count_res(ra[k], rb[k], xx);
+                nx += wk_count_res(ra[k], rb[k], x);
+                y += wk_count_res(ra[k], my_bx - 1 < rb[k] ? my_bx - 1 : rb[k], x);
+            }
+            m.lo = (int)((long)T * before / n_workers);
+            m.hi = (int)((long)T * (before + nx) / n_workers);
+            m.y = y; m.nx = nx;
+            // every worker of every XCD must hold its share: the largest share per worker is ceil(T / W) + 1 (rounding of the runs)
+            m.by_xcd = nx > 0 && (T + n_workers - 1) / n_workers + 1 <= WK_TILES;
+            return m;
+        };
         if (widx >= 0) {
-            if (!li_defer) sweep_tile_worker(widx, n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg, exp_mask);
+            if (!li_defer) sweep_tile_worker(make_map(bx, widx), nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k, status, lds, &s_wk_abort, dbg, exp_mask);
             return;
         }
         if (single && bx <= nstrips) {
@@ -3996,7 +4060,7 @@ sweep_persistent_kernel(double* A, long ldA, const int32_t* __restrict__ sel, in
                             (exp_mask & 8) != 0, wk, exp_mask);
             if (li_defer) return;
             __syncthreads();                                  // the strip's LDS is free
-            sweep_tile_worker(extra + n_idle_s + 3 + (strip - 4 * rp_blocks), n_workers, nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k,
+            sweep_tile_worker(make_map(bx, extra + n_idle_s + 3 + (strip - 4 * rp_blocks)), nblk, r_total, rp_blocks, ldA, Ypanel, wk, fl, sel, slot_k,
                               status, lds, &s_wk_abort, nullptr, exp_mask);
             return;
         }
@@ -4078,7 +4142,8 @@ static unsigned long long* sweep_dbg_buffer() { return nullptr; }
 // run into their bounded waits), bit 7 the rank update as a launch of its own (not fused into the sweep), bit 8 the time
 // stamps of scripts/sweep_stamps.py come from the LI pass instead of the HI pass, bit 9 a low-innovation update of rank <= 4
 // streams P at once instead of deferring its covariance to the high-innovation pass, bit 10 fault injection (the P H^T strips
-// announce their first Y block 2 ms late), bit 11 fault injection (the tile workers' polls are throttled to ~7 us each);
+// announce their first Y block 2 ms late), bit 11 fault injection (the tile workers' polls are throttled to ~7 us each), bit 12
+// the tile workers' tiles dealt round-robin over the worker index (the round-3 assignment) instead of XCD by XCD (WkMap);
 // set_sweep_exp_mask overrides the environment (tests)
 #if defined(RSLAM_DEBUG)
 static int g_sweep_exp_override = -1;

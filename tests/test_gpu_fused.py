@@ -72,6 +72,37 @@ def test_fused_update_equals_standalone_rank_update(hip_dbg, oracle_lib, compat,
     assert close_x(out[0]["x_new"], out[128]["x_new"], 1e-12) and close_P(out[0]["P_new"], out[128]["P_new"], 1e-11)
 
 
+@pytest.mark.parametrize("compat,L,H,seed", [(1, 300, 200, 2), (0, 300, 200, 2), (0, 90, 120, 13), (1, 150, 100, 5)])
+def test_xcd_tile_map_equals_round_robin_assignment_bitwise(hip_dbg, compat, L, H, seed):
+    """Which tile worker computes a tile pair of P - Y Y^T does not change a bit of it: the XCD-aware assignment of round 6
+    (kernels.hip WkMap: every XCD's workers own a contiguous run of the region-major tile sequence, so that an XCD's L2 fetches
+    ~16 of the Y row panels instead of all of them) against the round-3 assignment (tile widx + j W; RSLAM_SWEEP_EXP bit 12)
+    -- multi-block sweeps (C3 size, both arithmetic modes), a mid-size map, and a system of one diagonal block whose strips
+    join the workers late."""
+    fr = make_frame(L=L, H=H, seed=seed)
+    cfg = default_config(compat=compat, adaptive=0)
+    out = {}
+    for mask in (0, 4096):
+        hip_dbg.set_sweep_exp(mask)
+        try:
+            g = hip_dbg.RslamHip(cfg)
+            _, v0, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+            ic = (fr.ic & v0).astype(np.uint8)
+            g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+            for use_graph in (False, True, True):
+                g.step_frame(use_graph)
+            g.sync()
+            assert g.update_mode() == 2 and g.counters()["sweep_reruns"] == 0
+            out[mask] = g.fetch_results()
+            g.close()
+        finally:
+            hip_dbg.set_sweep_exp(-1)
+    a, b = out[0], out[4096]
+    assert int(a["li"].sum()) + int(a["hi"].sum()) > 0
+    assert np.array_equal(a["li"], b["li"]) and np.array_equal(a["hi"], b["hi"])
+    assert np.array_equal(a["x_new"], b["x_new"]) and np.array_equal(a["P_new"], b["P_new"])
+
+
 def test_alternating_frames_on_one_context(hip, oracle_lib):
     """The tile workers read Y while the strips of the same launch are still writing later blocks of it, through
     write-through stores and sc1 transfers.  A stale line would carry the PREVIOUS frame's Y: two different
