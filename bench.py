@@ -461,9 +461,43 @@ def main():
                             dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
+        # the same exchange as ONE 8-byte MAX all-reduce of (support << 32 | ~index) (north_star's literal collective; valid here:
+        # the benchmark frames have no adaptive stop): key fold + all-reduce + one-hot expansion timed on the same stream, and
+        # the frame it decides held against the all-gather form's.  Never allowed to take the line down: reported as a note.
+        allred = None
+        try:
+            from ransac_slam_amd.sharded import slice_key, expand_key
+            res_gather = ctx.fetch_results(want_P=False)
+            evr = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(20)]
+            red_all = torch.zeros_like(sf.all)
+            with eng.stream_context():
+                for e2 in evr:
+                    eng.step_phase(0, sf.begin, sf.end, sf.local)
+                    e2[0].record()
+                    key = slice_key(sf.local, sf.begin, sf.end - sf.begin)
+                    dist.all_reduce(key, op=dist.ReduceOp.MAX)
+                    expand_key(key, red_all, eng.H)
+                    e2[1].record()
+                    eng.step_phase(1, sf.begin, sf.end, red_all)
+            run.fence()
+            res_reduce = ctx.fetch_results(want_P=False)
+            same = all(int(res_gather[k]) == int(res_reduce[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")) \
+                and bool(np.array_equal(res_gather["x_new"], res_reduce["x_new"]))
+            mine_r = torch.tensor([float(np.median([e2[0].elapsed_time(e2[1]) * 1e3 for e2 in evr[5:]])), 1.0 if same else 0.0],
+                                  dtype=torch.float64, device="cuda")
+            allr_r = [torch.zeros_like(mine_r) for _ in range(world)]
+            dist.all_gather(allr_r, mine_r)
+            allred = {"per_rank_key_allreduce_expand_us": [round(float(t[0].item()), 2) for t in allr_r],
+                      "decides_the_same_frame_on_every_rank": all(float(t[1].item()) == 1.0 for t in allr_r),
+                      "bytes_reduced": 8,
+                      "note": "ShardedFrame(mode='allreduce') / rslam_shard_frame_allreduce: slice -> key, ncclAllReduce(MAX) of one "
+                              "int64, one-hot list; the timed region of this line uses the all-gather form"}
+        except Exception as e:                                  # noqa: BLE001
+            allred = {"note": "all-reduce form not measured: %r" % (e,)}
         if rank == 0:
             tab = np.array([t.cpu().numpy() for t in allr])
-            out["multi_gpu"] = {"per_rank_phase0_predict_score_us": [round(float(v), 2) for v in tab[:, 0]],
+            out["multi_gpu"] = {"allreduce_form": allred,
+                                "per_rank_phase0_predict_score_us": [round(float(v), 2) for v in tab[:, 0]],
                                 "per_rank_allgather_us": [round(float(v), 2) for v in tab[:, 1]],
                                 "per_rank_phase1_consensus_updates_us": [round(float(v), 2) for v in tab[:, 2]],
                                 "supports_bytes_gathered": int(4 * sf.chunk * world),

@@ -181,6 +181,26 @@ def test_sharded_frame_hip_engine_world1(hip):
         assert part[k] == full[k]
     assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
     c.close()
+    # ... and the exchange as one 8-byte key (mode="allreduce": slice_key / expand_key as torch ops on the engine's stream),
+    # on frames without the adaptive stop
+    cfg0 = default_config(compat=0, adaptive=0)
+    ref = hip.RslamHip(cfg0)
+    ref.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    ref.step_frame(False); ref.sync()
+    full0 = ref.fetch_results()
+    ref.close()
+    c = hip.RslamHip(cfg0)
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    sf = ShardedFrame(HipEngine(c, 0, use_graph=True), mode="allreduce")
+    for _ in range(3):
+        sf.step()
+    c.sync()
+    part = c.fetch_results()
+    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+        assert part[k] == full0[k]
+    assert np.array_equal(part["x_new"], full0["x_new"]) and np.array_equal(part["P_new"], full0["P_new"])
+    assert int((sf.all[:200] != 0).sum()) <= 1                  # the list phase 1 saw: the winner's support, nothing else
+    c.close()
 
 
 def _free_port():
@@ -207,9 +227,23 @@ def _two_rank_worker(rank, world, port, q):
             sf.step()
         c.sync()
         r = c.fetch_results()
-        q.put((rank, {k: int(r[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")},
-               r["x_new"].tobytes(), r["P_new"].tobytes(), sf.all[:257].cpu().tolist()))
+        gathered = sf.all[:257].cpu().tolist()
         c.close()
+        # the same two ranks with the one-key all-reduce (frames without the adaptive stop): against the all-gather form
+        c0 = api.RslamHip(default_config(compat=0, adaptive=0))
+        c0.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+        eng0 = HipEngine(c0, 0, use_graph=True)
+        res = {}
+        for mode in ("allgather", "allreduce"):
+            sfm = ShardedFrame(eng0, mode=mode)
+            for _ in range(2):
+                sfm.step()
+            c0.sync()
+            rm = c0.fetch_results()
+            res[mode] = ({k: int(rm[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")}, rm["x_new"].tobytes(), rm["P_new"].tobytes())
+        c0.close()
+        q.put((rank, {k: int(r[k]) for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi")},
+               r["x_new"].tobytes(), r["P_new"].tobytes(), gathered, res["allgather"] == res["allreduce"], res["allreduce"][0]))
     finally:
         dist.destroy_process_group()
 
@@ -240,11 +274,14 @@ def test_sharded_frame_hip_engine_two_ranks_one_device(hip):
         p.join(120)
         assert p.exitcode == 0
     for rank in (0, 1):
-        scal, xb, Pb, gathered = got[rank]
+        scal, xb, Pb, gathered, reduce_equals_gather, red_scal = got[rank]
         for k, v in scal.items():
             assert v == full[k], (rank, k)
         assert gathered == sup_full.tolist()
         assert xb == full["x_new"].tobytes() and Pb == full["P_new"].tobytes()
+        assert reduce_equals_gather, rank                       # one MAX all-reduce of 8 bytes decides the frame the all-gather decides
+        assert red_scal["hyps_evaluated"] == 257
+    assert got[0][5] == got[1][5]
 
 
 # --------------------------------------------------------------------------- unsynced pipeline
