@@ -37,8 +37,8 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_bench_c3_pmc_summary.csv")
-PMC_SUMMARY_C5 = os.path.join(ROOT, "profiles", "r05_bench_c5_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_bench_c3_pmc_summary.csv")
+PMC_SUMMARY_C5 = os.path.join(ROOT, "profiles", "r06_bench_c5_pmc_summary.csv")
 
 
 def pmc_traffic_bytes(kernel_substr, summary=None, pick=max):
@@ -581,7 +581,7 @@ def main():
                                   "algorithmic_bytes_per_launch": 8.0 * (2.0 * n5 * n5 + n5 * rr5),
                                   "traffic": traffic5,
                                   "traffic_note": "HBM bytes of the macro-tile launch + the 64 x 64 launch of the same pass (2 x FETCH_SIZE + "
-                                                  "WRITE_SIZE KiB, profiles/r05_bench_c5_pmc_summary.csv; null when older than the kernels)"},
+                                                  "WRITE_SIZE KiB, profiles/r06_bench_c5_pmc_summary.csv; null when older than the kernels)"},
                      "factor_sweep": {"launch_us": fs5, "rank_r": rr5, "algorithmic_flops": f5s,
                                       "achieved_TFLOPs": f5s / (fs5 * 1e-6) * 1e-12 if fs5 > 0 else 0.0,
                                       "frac_of_fp64_mfma_peak": f5s / (fs5 * 1e-6) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if fs5 > 0 else 0.0,

@@ -49,6 +49,8 @@ for i in range(N):
     if not ok:
         bad.append((case, compat, adaptive, k, int(r0["hi"].sum()), g.counters(), g.last_raw_status()))
     g.close()
+    if (i + 1) % 20 == 0:               # (a sign of life: a run that writes nothing for minutes is taken to be hung)
+        print("... %d frames, %d failures so far" % (i + 1, len(bad)), flush=True)
 print("frames", N, "skipped (reference assertion / margin audit)", skipped, "failures", len(bad))
 print("low-innovation counts met (compat, min(k, 3)) -> frames:", dict(sorted(hist.items())), " update modes:", modes)
 for b in bad:
