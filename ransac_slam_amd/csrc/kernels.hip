@@ -2698,6 +2698,20 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
     }
     static_for<0, NJ>([&](auto K) {
         constexpr int k = decltype(K)::value;
+        const bool mine = (g == (k & 1));                    // this group holds column block k
+        // (round 6) What the solve of step k needs of this strip itself is ready BEFORE L^-1(k) is: the column block (final since
+        // the update of step k-1: staged as the MFMA operand now) and, for the x update, the strip's X of step k-1 (still in Xs).
+        // Both happen in front of the wait, whose barrier orders them: behind the flag only the loads of L^-1 and of u^T (consumed
+        // behind the publication) and the MFMA chain are left -- the strips' step is a link of the hand-over loop that holds the
+        // chain workgroup's block period together with that workgroup's own sequence (see cdp_t_wave)
+        double xu0 = 0.0, xu1 = 0.0;
+        if (alive && k < nsteps) {
+            if (mine) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Sk[(16 * w + lq + 4 * reg) * 16 + ln] = acc[k >> 1][reg];
+            }
+            if (xrows && k > 0) { xu0 = Xs[(2 * xa.pair) * 16 + xa.row]; xu1 = Xs[(2 * xa.pair + 1) * 16 + xa.row]; }
+        }
         if (alive && k < nsteps) {
             sw_stamp(dbg, who, k, 0);
             // (P H^T strips of a fused launch also make sure u^T of the previous block is out: it has been for ~10 us)
@@ -2706,18 +2720,16 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
             sw_stamp(dbg, who, k, 1);
         }
         if (alive && k < nsteps) {
-            if (xrows && k > 0) xacc_add(xa, Xs, uT, ldA, k - 1);      // X of step k-1 is still in Xs (overwritten behind the next barrier)
-            const bool mine = (g == (k & 1));                // this group holds column block k
+            // (K9's share of step k-1, xacc_add in two halves: its u^T entries are requested first and consumed behind the publication)
+            double uu0 = 0.0, uu1 = 0.0;
+            if (xrows && k > 0) { uu0 = ld_coh(uT + (64L * (k - 1) + 2 * xa.pair) * ldA); uu1 = ld_coh(uT + (64L * (k - 1) + 2 * xa.pair + 1) * ldA); }
             const double* Lk = Linv + 64L * 64 * k;
             // L^-1 rows 16 w .. 16 w + 15 are zero right of column 16 w + 15: 4 (w + 1) MFMA steps
             double la[16];
             if (mine) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) la[q] = (q < 4 * (w + 1)) ? ld_coh(Lk + (16 * w + ln) + 64 * (4 * q + lq)) : 0.0;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Sk[(16 * w + lq + 4 * reg) * 16 + ln] = acc[k >> 1][reg];
             }
-            __syncthreads();
             if (mine) {
                 d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -2753,6 +2765,7 @@ __device__ __forceinline__ void sweep_strip(double* A, long ldA, int rp_blocks, 
                 }
                 if (publish && t == 0) __hip_atomic_store(&fl->y_flag[strip], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else __syncthreads();
+            if (xrows && k > 0) xa.part = fma(xu1, uu1, fma(xu0, uu0, xa.part));
             sw_stamp(dbg, who, k, 2);
             if (k < nupd) {
                 double xb[16];
@@ -2839,6 +2852,7 @@ struct CdpNext {                 // the inputs of the next block, as the strips 
     int need;                    // ... and the count that says they are all there
     int shards;                  // the counter is the sum of this many words, 32 ints apart (1, or 4: SweepFlags::tiles01s)
     double* Aop; double* Tpre;
+    bool need_a;                 // A(k+1,k) exists (false at the sweep's first block: only its diagonal tile is fetched)
 };
 // the hand-over counter of the next block's inputs (all its shards requested at once; the sum when it is used)
 __device__ __forceinline__ int cdp_count(const CdpNext& nx)
@@ -2933,7 +2947,9 @@ __device__ __forceinline__ void cdp_finish(const CdpNext& nx, CdShared& sh, doub
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            cdp_dma_issue<B>(nx, 0, lane_off); cdp_dma_issue<B>(nx, 1, lane_off); cdp_dma_issue<B>(nx, 2, lane_off); cdp_dma_issue<B>(nx, 3, lane_off);
+            // (the sweep's first block has no panel row: nothing would read the transfers, and their landing would be waited for below)
+            if (nx.need_a)
+            { cdp_dma_issue<B>(nx, 0, lane_off); cdp_dma_issue<B>(nx, 1, lane_off); cdp_dma_issue<B>(nx, 2, lane_off); cdp_dma_issue<B>(nx, 3, lane_off); }
             cdp_issue<B, 0>(nx, pf); cdp_issue<B, 1>(nx, pf); cdp_issue<B, 2>(nx, pf); cdp_issue<B, 3>(nx, pf);
         }
         cdp_store<B, 0>(nx, pf); cdp_store<B, 1>(nx, pf); cdp_store<B, 2>(nx, pf); cdp_store<B, 3>(nx, pf);
@@ -3156,6 +3172,18 @@ __device__ __forceinline__ int cdp_t_wave(CdShared& sh, int n_piv4, bool pending
         }
     }
 #undef CDP_T_LOADS
+    if (st == 4) {
+        // (round 6) the next block's inputs, as far as this wave fetched them, are LDS-resident BEFORE the end-of-chain barrier: the
+        // tile's values go to Tpre (read at the top of a block only: every T wave took its accumulators from it long ago) and
+        // the wave's LDS-DMA transfers are waited for here, under the inverse wave's last step, not behind the barrier.  One of
+        // three changes that only pay TOGETHER (with the strips' staging in front of their wait for L^-1 and no transfer at
+        // block 0): the block period is held by the chain workgroup's own sequence AND by the hand-over loop through the strips,
+        // each within 0.3 us of binding -- a cut on one side alone comes back as exposed latency on the other (DESIGN.md
+        // section 4, NOTEBOOK.md round 6: each of the three measured alone: nothing; together: C3 -2.2 us, five of five rounds)
+        cdp_store<B, 0>(nx, pf); cdp_store<B, 1>(nx, pf); cdp_store<B, 2>(nx, pf); cdp_store<B, 3>(nx, pf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st = 3;
+    }
     return st;
 }
 
@@ -3407,7 +3435,7 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             CdpNext cur;
             cur.a_base = A + (long)k * 64 + (long)(k > 0 ? k - 1 : 0) * 64 * ldA;
             cur.tile = A + (long)k * 64 + (long)k * 64 * ldA;
-            cur.ldA = ldA; cur.Aop = Aop; cur.Tpre = Tpre;
+            cur.ldA = ldA; cur.Aop = Aop; cur.Tpre = Tpre; cur.need_a = k > 0;
 #if defined(SW_TILES01_ONE)
             cur.flag = k <= 1 ? &fl->tiles01 : &fl->row_ready[k]; cur.need = k <= 1 ? n_lower_strips : 4; cur.shards = 1;
 #else
@@ -3475,7 +3503,7 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             CdpNext nx;
             nx.a_base = A + (long)(k + 1) * 64 + (long)k * 64 * ldA;
             nx.tile = A + (long)(k + 1) * 64 + (long)(k + 1) * 64 * ldA;
-            nx.ldA = ldA; nx.Aop = Aop; nx.Tpre = Tpre;
+            nx.ldA = ldA; nx.Aop = Aop; nx.Tpre = Tpre; nx.need_a = true;
 #if defined(SW_TILES01_ONE)
             nx.flag = k + 1 <= 1 ? &fl->tiles01 : &fl->row_ready[k + 1]; nx.need = k + 1 <= 1 ? n_lower_strips : 4; nx.shards = 1;
 #else
