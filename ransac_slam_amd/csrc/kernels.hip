@@ -3449,16 +3449,29 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
             // X = A(k,k-1) L^-T(k-1): Mf[m * CD_LD + c] = L^-1(c, m) is the B operand image as it stands.  L^-1 is lower
             // triangular: column tile tc of X only needs m < 16 (tc + 1); waves pair the column tiles {0,3} and {1,2}
             const int l = t & 63, lr = l >> 4, lc = l & 15;
-            constexpr int tr = ROLE >> 1;
+            auto x_tiles = [&](auto TR) {
+                constexpr int tr = decltype(TR)::value;
 #pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                const int tc = (ROLE & 1) ? 1 + o : 3 * o;
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[cdp_aop_index(kk + lr, 16 * tr + lc)],
-                                                               sh.Mf[(kk + lr) * CD_LD + 16 * tc + lc], acc, 0, 0, 0);
+                for (int o = 0; o < 2; ++o) {
+                    const int tc = (ROLE & 1) ? 1 + o : 3 * o;
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int kk = 0; kk < 16 * (tc + 1); kk += 4)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[cdp_aop_index(kk + lr, 16 * tr + lc)],
+                                                                   sh.Mf[(kk + lr) * CD_LD + 16 * tc + lc], acc, 0, 0, 0);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Xb[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
+                    for (int reg = 0; reg < 4; ++reg) Xb[(16 * tc + lc) * CD_LD + 16 * tr + lr + 4 * reg] = acc[reg];
+                }
+            };
+            // (round 6) The inverse wave's rows of L^-1(k-1) went out as write-through stores during the previous chain; the flag the strips
+            // wait for may only follow their acknowledgement.  Waiting for it between the two barriers held the whole workgroup
+            // for a store round trip; now the inverse wave waits HERE, beside the X product, and the T wave that shares its SIMD
+            // forms its two tiles (the matrix pipe of that SIMD sees the same 40 products)
+            if constexpr (ROLE == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((t & 63) == 0) __hip_atomic_store(&fl->linv_ready, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                x_tiles(std::integral_constant<int, (ROLE >> 1)>{});
+                if constexpr (ROLE == 5) x_tiles(std::integral_constant<int, 0>{});
             }
         }
         __syncthreads();
@@ -3515,9 +3528,12 @@ __device__ __forceinline__ void cdp_role(double* lds, double* A, long ldA, int n
         }
         __syncthreads();                                  // the chain of block k has ended: L^-1(k) is complete in Mf
         if constexpr (ROLE == 1) {
-            // the inverse wave's rows of L^-1(k) have reached memory: the strips may fetch them (under the other waves' top of the next block)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if ((t & 63) == 0) __hip_atomic_store(&fl->linv_ready, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the inverse wave's rows of L^-1(k) have reached memory: the strips may fetch them
+            if (k + 1 >= nblk)          // (the last block: nothing follows; otherwise beside the next block's X product, see above)
+            {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((t & 63) == 0) __hip_atomic_store(&fl->linv_ready, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (stamp && t == 0) stamp[5] = wall_clock64();
         if (sh.timeout) { if (t == 0) sw_timed_out(status, sh.timeout == 5 ? -35 : -(36 + 10 * k), k); return; }     // hand-over protocol broke (never expected)
