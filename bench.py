@@ -351,7 +351,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--compat", type=int, default=1, help="1 = reference-identical arithmetic (default), 0 = corrected")
     ap.add_argument("--dedup", type=int, default=0)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="hand the frames to the device as hipGraph replays instead of stream-ordered launches")
+    ap.add_argument("--no-graph", action="store_true", help="(the default since round 6; accepted for the scripts of earlier rounds)")
     ap.add_argument("--cpu-sample-iters", type=int, default=1000,
                     help="RANSAC iterations of the CPU baseline actually timed (default: all 1000 of C3 = one whole frame, ~6 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -404,7 +405,11 @@ def main():
             os._exit(3)                                     # (not sys.exit: a hung communicator would block interpreter shutdown)
 
     wl = WORKLOADS[args.workload]
-    use_graph = not args.no_graph
+    # Stream-ordered launches (seven per C3 frame), not hipGraph replay: on this runtime the device idles ~8 us between two replays
+    # of a graph (kernel trace: the gap in front of each replay's first kernel; none between stream-ordered launches), the host
+    # enqueues a frame's launches in a fraction of its device time -- bench.py 0.186-0.189 against 0.193-0.196 ms per C3 step in
+    # interleaved runs (profiles/r06_launch_mode_ab.txt).  --graph times the replay.
+    use_graph = bool(args.graph)
     run = Runner(args, wl, world, rank, local_rank, args.compat, use_graph)
     ctx, frame, ic, m = run.ctx, run.frame, run.ic, run.m
     H_total, H_local = run.H_total, run.H_local
@@ -421,7 +426,7 @@ def main():
                 "matched_features": r.m, "hypotheses_total": r.H_total, "hypotheses_per_gpu": r.H_local,
                 "compat": int(r.cfg.compat), "adaptive": 0, "dedup": args.dedup,
                 "launch": ("eager stream, host-sized launch sequence (update counts read from host-mapped memory)" if host_sized else
-                           "eager stream" if args.no_graph else
+                           "stream-ordered launches" if not use_graph else
                            ("hipGraph replay" if world == 1 else "two hipGraphs per frame around the all-gather")),
                 "parallelism": f"hypothesis-sharded x{world}, replicated update" if world > 1 else "single GPU"}
 
@@ -604,7 +609,7 @@ def main():
         acc, outl, med_total = eager_stage_times(ctx, nrep)
         out["stage_us"] = stage_dict(acc, ctx, int(run.cfg.compat), 2)
         out["stage_note"] = ("eager frames with a hipEvent between the stages (each record costs the stream ~5 us: the sum is well above "
-                             "ms_per_step, which is hipGraph replay without events).  null = the mode has no such launch: the rank "
+                             "ms_per_step, which is the same launches without events).  null = the mode has no such launch: the rank "
                              "update of a fused sweep runs inside the sweep's launch (factor_*_us), and with compat = 1 the one- or "
                              "two-inlier low-innovation update runs INSIDE the consensus launch (select_us): the sequence has no "
                              "low-innovation sweep at all")

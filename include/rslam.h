@@ -250,7 +250,11 @@ int rslam_step_score(rslam_ctx* ctx, int32_t hyp_begin, int32_t hyp_end,
 int rslam_step_update(rslam_ctx* ctx, const int32_t* d_supports);
 
 /* Whole frame = step_predict + step_score(0, n_draws) + step_update with a
- * context-owned support buffer; replayed from a hipGraph when use_graph != 0. */
+ * context-owned support buffer; replayed from a hipGraph when use_graph != 0.
+ * Which to use: the replay is ONE host call per frame (7-9 us of host time on the measured host instead of ~22 for the frame's
+ * seven launches), but the runtime leaves the device idle for ~8 us in front of every replay and not between stream-ordered
+ * launches (ROCm 7.2, kernel trace: DESIGN.md section 4, "hipGraph"): frames enqueued back to back are ~4 % faster with
+ * use_graph = 0 as long as the host stays ahead of the device; use_graph = 1 is for hosts that do not. */
 int rslam_step_frame(rslam_ctx* ctx, int32_t use_graph);
 
 /* The same frame in two hipGraph-replayed halves for the hypothesis-sharded (multi-GPU) case:

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_slam_amd import api, default_config
 from ransac_slam_amd.synth import make_frame
 DEBUG = "--debug" in sys.argv         # time the diagnostic variant (RSLAM_HIP_LIB_DEBUG=<a build of ransac_slam_amd.build.build_dev>)
-sys.argv = [a for a in sys.argv if a != "--debug"]
+GRAPH = "--eager" not in sys.argv     # --eager: the frames of the timed loops as stream-ordered launches, no hipGraph replay
+sys.argv = [a for a in sys.argv if a not in ("--debug", "--eager")]
 compat = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L, H, seed = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (300, 1000, 2)
 fr = make_frame(L=L, H=H, seed=seed)
@@ -16,13 +17,13 @@ ctx.step_predict(); ctx.sync()
 ic = fr.ic & ctx.fetch_prediction()[1]
 ctx.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
 for _ in range(30):
-    ctx.step_frame(True)
+    ctx.step_frame(GRAPH)
 ctx.sync()
 out = []
 for _ in range(5):
     t0 = time.perf_counter()
     for _ in range(200):
-        ctx.step_frame(True)
+        ctx.step_frame(GRAPH)
     ctx.sync()
     out.append((time.perf_counter() - t0) / 200 * 1e3)
 r = ctx.fetch_results(want_P=False)

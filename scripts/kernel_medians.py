@@ -15,3 +15,17 @@ for k, d in by.items():
             a = st.median(d); tot += a
             print("  %-30s n=%d  median %.2f" % (k, len(d), a))
 print("  sum of medians per frame %.2f us" % tot)
+# the idle time in front of each launch (its start minus the previous launch's end), median per kernel, steady-state frames only
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+gaps = {}
+for a, b in zip(rows[:-1], rows[1:]):
+    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    if g < 50.0:          # (not the pauses between timed regions)
+        gaps.setdefault(b["Kernel_Name"].split("(")[0][-30:], []).append(g)
+gtot = 0.0
+for k, d in gaps.items():
+    if len(d) > 500:
+        per_frame = len(d) / max(nframes, 1)
+        gtot += st.median(d) * round(per_frame)
+        print("  gap in front of %-30s n=%d  median %.2f  p90 %.2f" % (k, len(d), st.median(d), sorted(d)[int(0.9 * len(d))]))
+print("  sum of median gaps per frame %.2f us" % gtot)
