@@ -167,20 +167,21 @@ def test_sharded_frame_hip_engine_world1(hip):
     ref.step_frame(False); ref.sync()
     full = ref.fetch_results()
     ref.close()
-    c = hip.RslamHip(cfg)
-    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
-    assert torch.cuda.current_stream().cuda_stream == 0
-    eng = HipEngine(c, 0, use_graph=True)
-    assert eng.stream.cuda_stream != 0
-    sf = ShardedFrame(eng)
-    for _ in range(3):
-        sf.step()
-    c.sync()
-    part = c.fetch_results()
-    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
-        assert part[k] == full[k]
-    assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
-    c.close()
+    for use_graph in (False, True):          # (stream-ordered launches: what bench.py --gpus N times; two hipGraphs per frame)
+        c = hip.RslamHip(cfg)
+        c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+        assert torch.cuda.current_stream().cuda_stream == 0
+        eng = HipEngine(c, 0, use_graph=use_graph)
+        assert eng.stream.cuda_stream != 0
+        sf = ShardedFrame(eng)
+        for _ in range(3):
+            sf.step()
+        c.sync()
+        part = c.fetch_results()
+        for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+            assert part[k] == full[k]
+        assert np.array_equal(part["x_new"], full["x_new"]) and np.array_equal(part["P_new"], full["P_new"])
+        c.close()
     # ... and the exchange as one 8-byte key (mode="allreduce": slice_key / expand_key as torch ops on the engine's stream),
     # on frames without the adaptive stop
     cfg0 = default_config(compat=0, adaptive=0)
@@ -191,7 +192,7 @@ def test_sharded_frame_hip_engine_world1(hip):
     ref.close()
     c = hip.RslamHip(cfg0)
     c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
-    sf = ShardedFrame(HipEngine(c, 0, use_graph=True), mode="allreduce")
+    sf = ShardedFrame(HipEngine(c, 0, use_graph=False), mode="allreduce")
     for _ in range(3):
         sf.step()
     c.sync()
@@ -221,7 +222,7 @@ def _two_rank_worker(rank, world, port, q):
         fr = make_frame(L=60, H=257, seed=302)
         c = api.RslamHip(default_config(compat=0, adaptive=1))
         c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
-        eng = HipEngine(c, 0, use_graph=True)
+        eng = HipEngine(c, 0, use_graph=False)          # (stream-ordered launches, as bench.py --gpus N; eng0 below replays hipGraphs)
         sf = ShardedFrame(eng)
         for _ in range(3):
             sf.step()
