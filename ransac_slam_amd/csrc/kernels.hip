@@ -518,6 +518,7 @@ void launch_distort_probe(hipStream_t s, const Cam& cam, int n, const double* uv
     distort_probe_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(cam, n, uv, out_score, out_ref);
 }
 
+template <bool ROT>
 __global__ void __launch_bounds__(1024)
 score_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
              const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m, int words,
@@ -532,8 +533,14 @@ score_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W
     hyp_setup(x, W, NP, wv, p, hc, tab.hctx);
     __syncthreads();
     int local = 0;
+    // Which wave takes which 64 features of a pass rotates with the workgroup: where the last pass is partial (300 features in
+    // workgroups of four waves: the fifth chunk) the extra chunk falls on a different wave -- and with it on a different SIMD --
+    // from one workgroup to the next.  (Round 6: as workgroups of FIVE waves the hardware put two waves of every workgroup on
+    // the same SIMD of its compute unit: that SIMD carried 40 % of the instructions and capped the residency at three workgroups.)
+    // (ROT: workgroups of exactly four waves)
+    const int chunk = ROT ? (((int)(threadIdx.x >> 6) + (int)blockIdx.x) & 3) : (int)(threadIdx.x >> 6);
     for (int base = 0; base < m; base += blockDim.x) {
-        const int j = base + threadIdx.x;
+        const int j = base + 64 * chunk + (int)(threadIdx.x & 63);
         const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);
         const unsigned long long bal = __ballot(inl);
         if ((threadIdx.x & 63) == 0) {
@@ -556,6 +563,20 @@ static inline int score_block_size(int m)
     if (bs > 1024) bs = 1024;
     return bs;
 }
+// The scoring launch proper.  A LONG hypothesis list (>= SCORE_BALANCED_MIN entries: 4000 hypotheses on one GPU, the x16 grid of
+// bench.py) with more than four waves' worth of features that is not a multiple of four waves runs as workgroups of FOUR waves
+// with a partial last pass, whose extra chunk score_kernel rotates over the waves: one wave per SIMD, seven workgroups resident
+// (16 000 hypotheses x 300 features: 93-95 us against 107 as workgroups of five waves).  A list that is resident at once anyway
+// (1000 hypotheses) keeps one pass per wave: there the wave with two passes is the launch's critical path (+0.5 us).
+constexpr int SCORE_BALANCED_MIN = 2048;
+static inline int score_launch_block_size(int m, int n_entries)
+{
+    const int bs = score_block_size(m);
+#if defined(RSLAM_DEBUG)
+    if (getenv("RSLAM_SCORE_ONE_PASS")) return bs;           // (tests: the two forms against each other)
+#endif
+    return (n_entries >= SCORE_BALANCED_MIN && bs > 256 && (bs / 64) % 4 != 0) ? 256 : bs;
+}
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
                   const double* wv, const ScoreTables& tab, const double* z, int m, int words,
@@ -563,8 +584,9 @@ void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* 
                   uint64_t* masks_out)
 {
     if (n_entries <= 0 || m <= 0) return;
-    score_kernel<<<dim3(n_entries), dim3(score_block_size(m)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list,
-                                                                   threshold, sup_out, masks_out);
+    const int bs = score_launch_block_size(m, n_entries);
+    if (bs != score_block_size(m)) score_kernel<true><<<dim3(n_entries), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list, threshold, sup_out, masks_out);
+    else score_kernel<false><<<dim3(n_entries), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list, threshold, sup_out, masks_out);
 }
 
 __global__ void map_support_kernel(const int32_t* __restrict__ possup, const int32_t* __restrict__ pos,

@@ -149,3 +149,40 @@ def test_far_projections_take_the_reference_sequence(hip, oracle_lib):
         D = 1 + cam.k1 * rd ** 2 + cam.k2 * rd ** 4
         return np.stack([xu / D / cam.dx + cam.Cx, yu / D / cam.dy + cam.Cy], axis=1)
     assert np.max(np.abs(six(uv[:, 0], uv[:, 1]) - ref)) > 10.0
+
+
+@pytest.mark.parametrize("L,H,compat,frac_cartesian", [
+    (300, 4000, 1, 0.0),        # C4 on one GPU: five chunks of features, the fifth partly used
+    (300, 4000, 0, 0.0),
+    (300, 2048, 0, 0.0),        # the shortest list that is scored this way
+    (400, 2100, 0, 0.3),        # seven chunks (two passes, three chunks in the second), both feature types
+    (600, 2050, 1, 0.0),        # ten chunks: three passes
+])
+def test_four_wave_scoring_workgroups_equal_one_pass_per_wave(hip, L, H, compat, frac_cartesian):
+    """Long hypothesis lists are scored by workgroups of four waves that take the features in passes of 256, the extra chunk of
+    the last pass on a different wave from one workgroup to the next (kernels.hip score_kernel<true>); the supports and the
+    64-bit inlier masks of every hypothesis must be those of the one-pass-per-wave launch (RSLAM_SCORE_ONE_PASS in the
+    diagnostic library): which wave scores a feature changes nothing."""
+    fr = make_frame(L=L, H=H, seed=31 + L, frac_cartesian=frac_cartesian)
+    cfg = default_config(compat=compat, adaptive=0)
+    out = {}
+    for one_pass in (True, False):
+        if one_pass:
+            os.environ["RSLAM_SCORE_ONE_PASS"] = "1"
+        try:
+            g = hip.RslamHip(cfg, debug=True)
+            _, v0, _ = g.predict(fr.types, fr.x_pred, fr.P_pred)
+            ic = (fr.ic & v0).astype(np.uint8)
+            assert int(ic.sum()) > 256 and ((int(ic.sum()) + 63) // 64) % 4 != 0          # (a shape the four-wave form takes)
+            g.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, ic, fr.draws)
+            g.step_frame(False); g.sync()
+            sup, masks = g.fetch_supports()
+            res = g.fetch_results(want_P=False)
+            out[one_pass] = (sup.copy(), masks.copy(), res["best_hyp"], res["best_support"], res["li"].copy(), res["hi"].copy())
+            g.close()
+        finally:
+            os.environ.pop("RSLAM_SCORE_ONE_PASS", None)
+    a, b = out[True], out[False]
+    assert a[0].shape == (H,) and int(a[0].max()) > 0
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and a[3] == b[3] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
