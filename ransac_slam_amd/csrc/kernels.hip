@@ -563,19 +563,23 @@ static inline int score_block_size(int m)
     if (bs > 1024) bs = 1024;
     return bs;
 }
-// The scoring launch proper.  A LONG hypothesis list (>= SCORE_BALANCED_MIN entries: 4000 hypotheses on one GPU, the x16 grid of
-// bench.py) with more than four waves' worth of features that is not a multiple of four waves runs as workgroups of FOUR waves
-// with a partial last pass, whose extra chunk score_kernel rotates over the waves: one wave per SIMD, seven workgroups resident
-// (16 000 hypotheses x 300 features: 93-95 us against 107 as workgroups of five waves).  A list that is resident at once anyway
-// (1000 hypotheses) keeps one pass per wave: there the wave with two passes is the launch's critical path (+0.5 us).
-constexpr int SCORE_BALANCED_MIN = 2048;
+// The scoring launch proper.  A workgroup of one pass per wave is the fastest form as long as the whole list is resident at once
+// (the frame's 1000 hypotheses x 5 waves): there a wave with two passes would be the launch's critical path (+0.5 us measured).
+// A launch of MORE waves than the device holds (> SCORE_RESIDENT_WAVES: 4000 hypotheses on one GPU, the x16 grid of bench.py,
+// 1000 hypotheses x 16 waves at 1000 landmarks) with more than four waves' worth of features runs as workgroups of FOUR waves
+// that take the features in passes of 256, the extra chunk of a partial last pass rotating over the waves (score_kernel<true>):
+// one wave per SIMD and seven workgroups resident, where five waves per workgroup put two on one SIMD (3.25 of 7 possible
+// waves resident, that SIMD with 40 % of the instructions) and sixteen leave room for one workgroup per compute unit.
+// 16 000 x 300: 92 us against 104; 4 000 x 300: 30.9 against 32.7; 1 000 x 1000 (C5): 34 against 38.5; 4 000 x 1000: 83-92
+// against 110 (profiles/r06_score_variants.txt).
+constexpr long SCORE_RESIDENT_WAVES = 8192;
 static inline int score_launch_block_size(int m, int n_entries)
 {
     const int bs = score_block_size(m);
 #if defined(RSLAM_DEBUG)
     if (getenv("RSLAM_SCORE_ONE_PASS")) return bs;           // (tests: the two forms against each other)
 #endif
-    return (n_entries >= SCORE_BALANCED_MIN && bs > 256 && (bs / 64) % 4 != 0) ? 256 : bs;
+    return (bs > 256 && (long)n_entries * (bs / 64) > SCORE_RESIDENT_WAVES) ? 256 : bs;
 }
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,

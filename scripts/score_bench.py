@@ -1,4 +1,4 @@
-"""the scoring launch (K4) of the C3 frame on its own: hipEvent time of the stage for H = 1000 (one frame), 4000 (C4 on one GPU) and
+"""the scoring launch (K4) of the C3 frame (--L 1000: of the C5 frame) on its own: hipEvent time of the stage for H = 1000 (one frame), 4000 (C4 on one GPU) and
 16 000 hypotheses (the x16 grid of bench.py), both arithmetic modes; supports and masks against the product library.
    [RSLAM_HIP_LIB_DEBUG=ransac_slam_amd/_dev/<name>.so] python scripts/score_bench.py [--debug]"""
 import os, sys
@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_slam_amd import api, default_config
 from ransac_slam_amd.synth import make_frame
 DEBUG = "--debug" in sys.argv
-fr = make_frame(L=300, H=1000, seed=2)
+L = int(sys.argv[sys.argv.index("--L") + 1]) if "--L" in sys.argv else 300          # (--L 1000: the C5 map)
+MULTS = (1, 4, 16) if L <= 300 else (1, 4)
+fr = make_frame(L=L, H=1000, seed=2 if L == 300 else 4)
 for compat in (1, 0):
     cfg = default_config(compat=compat, adaptive=0)
     probe = api.RslamHip(cfg)
@@ -17,7 +19,7 @@ for compat in (1, 0):
     probe.close()
     m = int(ic.sum())
     line = []
-    for mult in (1, 4, 16):
+    for mult in MULTS:
         draws = np.random.default_rng(99).random(mult * 1000)
         res = {}
         for dbg in ((False, True) if DEBUG else (False,)):
