@@ -563,8 +563,9 @@ static inline int score_block_size(int m)
     if (bs > 1024) bs = 1024;
     return bs;
 }
-// The scoring launch proper.  A workgroup of one pass per wave is the fastest form as long as the whole list is resident at once
-// (the frame's 1000 hypotheses x 5 waves): there a wave with two passes would be the launch's critical path (+0.5 us measured).
+// The scoring launch for chunk counts that score_spare_kernel (below) does not take: multiples of four, and more than eight.
+// A workgroup of one pass per wave is the fastest form as long as the whole list is resident at once: there a wave with two
+// passes would be the launch's critical path (+0.5 us measured at 1000 x 300).
 // A launch of MORE waves than the device holds (> SCORE_RESIDENT_WAVES: 4000 hypotheses on one GPU, the x16 grid of bench.py,
 // 1000 hypotheses x 16 waves at 1000 landmarks) with more than four waves' worth of features runs as workgroups of FOUR waves
 // that take the features in passes of 256, the extra chunk of a partial last pass rotating over the waves (score_kernel<true>):
@@ -573,13 +574,61 @@ static inline int score_block_size(int m)
 // 16 000 x 300: 92 us against 104; 4 000 x 300: 30.9 against 32.7; 1 000 x 1000 (C5): 34 against 38.5; 4 000 x 1000: 83-92
 // against 110 (profiles/r06_score_variants.txt).
 constexpr long SCORE_RESIDENT_WAVES = 8192;
+static bool score_one_pass_only()                           // (diagnostic variant of the library -- tests: the forms against each other)
+{
+#if defined(RSLAM_DEBUG)
+    return getenv("RSLAM_SCORE_ONE_PASS") != nullptr;
+#else
+    return false;
+#endif
+}
 static inline int score_launch_block_size(int m, int n_entries)
 {
     const int bs = score_block_size(m);
-#if defined(RSLAM_DEBUG)
-    if (getenv("RSLAM_SCORE_ONE_PASS")) return bs;           // (tests: the two forms against each other)
-#endif
+    if (score_one_pass_only()) return bs;
     return (bs > 256 && (long)n_entries * (bs / 64) > SCORE_RESIDENT_WAVES) ? 256 : bs;
+}
+
+// One pass per wave WITHOUT the fifth wave on the first wave's SIMD: C = 4 a + b chunks of 64 features (b = 1..3) are launched as
+// 4 (a + 1) waves; of the last four -- one per SIMD -- b take a chunk, WHICH ones rotates with the workgroup, the others leave
+// at once (a wave that has ended does not count at the barriers).  The hardware deals a workgroup's waves to the four SIMDs of
+// its compute unit in turn, starting at the same SIMD every time: five waves put waves 0 and 4 of EVERY workgroup on it -- 2 of
+// 5 passes, 1.6 times the average, and 3.25 of 7 possible waves resident per SIMD in a long launch (scripts/pmc_score.sh).
+// C3's scoring launch 8.9 us against 10.2 as a kernel; 4 000 hypotheses 27.3 against 32.7; 16 000: 81 against 104 = 5.6-5.8 TB/s
+// of the nominal 96 B per pair, 0.70-0.72 of the roof (round 5: 0.56); bit-identical (profiles/r06_score_variants.txt).
+__global__ void __launch_bounds__(1024)
+score_spare_kernel(Cam cam, const double* __restrict__ x, const double* __restrict__ W, int NP,
+                   const double* __restrict__ wv, ScoreTables tab, const double* __restrict__ z, int m, int words,
+                   const int32_t* __restrict__ pos_list, int C, double thr, int32_t* __restrict__ sup_out,
+                   uint64_t* __restrict__ masks_out)
+{
+    __shared__ int s_count;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int a4 = C & ~3, b = C & 3;
+    int chunk = wave;
+    if (wave >= a4) {
+        const int k = (wave - a4 - (int)blockIdx.x) & 3;
+        if (k >= b) return;
+        chunk = a4 + k;
+    }
+    const int e = blockIdx.x;
+    const int p = pos_list ? pos_list[e] : e;
+    // (the workgroup's count is kept by the wave that holds chunk 0 -- with fewer than four chunks wave 0 may be one that left)
+    const bool leader = chunk == 0 && (threadIdx.x & 63) == 0;
+    if (leader) s_count = 0;
+    HypCtx hc;
+    hyp_setup(x, W, NP, wv, p, hc, tab.hctx);
+    __syncthreads();
+    const int j = 64 * chunk + (int)(threadIdx.x & 63);
+    const bool inl = (j < m) && score_pair(cam, x, hc, tab, z, j, thr);
+    const unsigned long long bal = __ballot(inl);
+    if ((threadIdx.x & 63) == 0 && chunk < words) {
+        if (masks_out) masks_out[(long)e * words + chunk] = bal;
+        const int cnt = __popcll(bal);
+        if (cnt) atomicAdd(&s_count, cnt);
+    }
+    __syncthreads();
+    if (leader) sup_out[e] = s_count;
 }
 
 void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* W, int NP,
@@ -588,6 +637,12 @@ void launch_score(hipStream_t s, const Cam& cam, const double* x, const double* 
                   uint64_t* masks_out)
 {
     if (n_entries <= 0 || m <= 0) return;
+    const int C = score_block_size(m) / 64;              // chunks of 64 features
+    if (m <= 64 * C && C >= 3 && C <= 8 && (C % 4) != 0 && !score_one_pass_only()) {
+        score_spare_kernel<<<dim3(n_entries), dim3(64 * ((C & ~3) + 4)), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list, C, threshold,
+                                                                            sup_out, masks_out);
+        return;
+    }
     const int bs = score_launch_block_size(m, n_entries);
     if (bs != score_block_size(m)) score_kernel<true><<<dim3(n_entries), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list, threshold, sup_out, masks_out);
     else score_kernel<false><<<dim3(n_entries), dim3(bs), 0, s>>>(cam, x, W, NP, wv, tab, z, m, words, pos_list, threshold, sup_out, masks_out);
@@ -701,8 +756,11 @@ __device__ __forceinline__ int block_incl_sum(int v, int* s_w, int* total)
 // all threads of the block; blockDim.x <= SEL_MAX_THREADS and a multiple of 64; result in sel[0..2]
 __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const int32_t* __restrict__ nhyp_table,
                                  int adaptive, int n_hyp_init, int32_t* __restrict__ sel,
-                                 int* s_max, int* s_cnt, int* s_rec, int* s_nh)
+                                 int* s_max, int* s_cnt, int* s_rec, int* s_nh, int m /* the table has m + 1 entries */)
 {
+    // (a support is a count of matched features, 0 .. m; the list may come from the caller -- other ranks -- and indexes the table:
+    //  a value outside that range must not become an address)
+    auto nhyp_of = [&](int support) { return nhyp_table[support < 0 ? 0 : support > m ? m : support]; };
     const int t = threadIdx.x, nt = blockDim.x;
     const int chunk = (H + nt - 1) / nt;
     const int lo = min(H, t * chunk), hi = min(H, lo + chunk);
@@ -723,7 +781,7 @@ __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const i
         if (v > run) { run = v; if (wpos < SEL_MAX_RECORDS) { s_rec[wpos] = i; if (wpos < SEL_MAX_THREADS) s_cnt[wpos] = v; } ++wpos; }
     }
     __syncthreads();
-    if (adaptive && t < min(total, SEL_MAX_THREADS)) s_nh[t] = nhyp_table[s_cnt[t]];
+    if (adaptive && t < min(total, SEL_MAX_THREADS)) s_nh[t] = nhyp_of(s_cnt[t]);
     if (t == 0) s_max[0] = total;
     __syncthreads();
     if (t == 0) {
@@ -736,7 +794,7 @@ __device__ void select_consensus(const int32_t* __restrict__ sup, int H, const i
             if (i >= n_hyp || i >= H) break;           // loop ended before reaching this record
             best = k < SEL_MAX_THREADS ? s_cnt[k] : sup[i]; besti = i; last = i + 1;   // (the record's support sits beside its index)
             if (adaptive) {
-                n_hyp = k < SEL_MAX_THREADS ? s_nh[k] : nhyp_table[best];
+                n_hyp = k < SEL_MAX_THREADS ? s_nh[k] : nhyp_of(best);
                 if (n_hyp == 0 || i > n_hyp) { evaluated = i + 1; done = true; }   // the two breaks, :533,:536
             }
         }
@@ -912,7 +970,7 @@ __device__ void best_mask_body(const Cam& cam, const double* __restrict__ x, con
     const int j0 = threadIdx.x;
     int feat0 = -1;
     if (j0 < m) feat0 = tab.feat[j0];
-    select_consensus(sa.sup, sa.H, sa.nhyp_table, sa.adaptive, sa.n_hyp_init, sel, s_max, s_cnt, s_rec, s_nh);   // K5
+    select_consensus(sa.sup, sa.H, sa.nhyp_table, sa.adaptive, sa.n_hyp_init, sel, s_max, s_cnt, s_rec, s_nh, m);   // K5
     if (threadIdx.x == 0) *s_running = 0;
     for (int i = threadIdx.x; i < sa.L; i += blockDim.x) li[i] = 0;
     __syncthreads();

@@ -249,6 +249,42 @@ def test_sharded_scoring_equals_full(hip):
     c.close()
 
 
+def test_supports_outside_their_range_do_not_become_addresses(hip):
+    """rslam_step_update takes the support list from the caller (other ranks): a value that is not a count of matched features
+    must not index the adaptive-stop table (m + 1 entries) out of bounds -- garbage in, a posterior of garbage out, but no fault,
+    and the context works on."""
+    import torch
+    fr = make_frame(L=60, H=257, seed=302)
+    cfg = default_config(compat=0, adaptive=1)
+    c = hip.RslamHip(cfg)
+    c.load_frame(fr.types, fr.x_pred, fr.P_pred, fr.z, fr.ic, fr.draws)
+    c.step_frame(False); c.sync()
+    full = c.fetch_results()
+    sup_full, _ = c.fetch_supports()
+    bad = torch.tensor(sup_full, dtype=torch.int32, device="cuda:0")
+    bad[3] = 2_000_000_000
+    bad[5] = -7
+    torch.cuda.synchronize()
+    c.step_predict()
+    c.step_score(0, 257, torch.zeros(257, dtype=torch.int32, device="cuda:0").data_ptr())
+    c.step_update(bad.data_ptr())
+    try:
+        c.sync()                                    # (whatever status: the hypothesis with the absurd support "wins")
+    except hip.RslamError:
+        pass
+    good = torch.tensor(sup_full, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    c.step_predict()
+    c.step_score(0, 257, torch.zeros(257, dtype=torch.int32, device="cuda:0").data_ptr())
+    c.step_update(good.data_ptr())
+    c.sync()
+    again = c.fetch_results()
+    for k in ("best_hyp", "best_support", "hyps_evaluated", "n_li", "n_hi"):
+        assert again[k] == full[k]
+    assert np.array_equal(again["x_new"], full["x_new"]) and np.array_equal(again["P_new"], full["P_new"])
+    c.close()
+
+
 def test_launch_sequence_independent_of_inlier_counts(hip, oracle_lib):
     """The update stage is sized on the host without looking at any earlier frame: the persistent sweep is ONE launch sized
     for the largest inlier count the frame can have (idle strips become tile workers), so frames whose inlier counts go
