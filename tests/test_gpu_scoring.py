@@ -156,7 +156,7 @@ def test_far_projections_take_the_reference_sequence(hip, oracle_lib):
     (300, 1000, 0, 0.0),
     (300, 4001, 1, 0.0),        # C4 on one GPU (+1)
     (150, 500, 0, 0.3),         # three chunks, both feature types
-    (370, 300, 1, 0.2),         # six chunks: 4 + 2 of the last four waves
+    (370, 300, 0, 0.2),         # six chunks: 4 + 2 of the last four waves
     (400, 2100, 0, 0.3),        # seven chunks: 4 + 3 of the last four waves
     (600, 2050, 1, 0.0),        # ten chunks, more waves than the device holds: workgroups of four waves, three passes
     (1000, 1000, 0, 0.0),       # C5: sixteen chunks, four full passes -- one workgroup per compute unit in the one-pass form
