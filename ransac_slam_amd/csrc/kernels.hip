@@ -569,10 +569,9 @@ static inline int score_block_size(int m)
 // A launch of MORE waves than the device holds (> SCORE_RESIDENT_WAVES: 4000 hypotheses on one GPU, the x16 grid of bench.py,
 // 1000 hypotheses x 16 waves at 1000 landmarks) with more than four waves' worth of features runs as workgroups of FOUR waves
 // that take the features in passes of 256, the extra chunk of a partial last pass rotating over the waves (score_kernel<true>):
-// one wave per SIMD and seven workgroups resident, where five waves per workgroup put two on one SIMD (3.25 of 7 possible
-// waves resident, that SIMD with 40 % of the instructions) and sixteen leave room for one workgroup per compute unit.
-// 16 000 x 300: 92 us against 104; 4 000 x 300: 30.9 against 32.7; 1 000 x 1000 (C5): 34 against 38.5; 4 000 x 1000: 83-92
-// against 110 (profiles/r06_score_variants.txt).
+// one wave per SIMD and seven workgroups resident, where sixteen waves per workgroup leave room for one workgroup per compute
+// unit.  1 000 x 1000 (C5): 34 us against 38.5; 4 000 x 1000: 83-92 against 110.  (Five chunks in this form: 16 000 x 300 in 92 us
+// against 104 as five-wave workgroups -- and 81 with spare waves, which is what five chunks get: profiles/r06_score_variants.txt.)
 constexpr long SCORE_RESIDENT_WAVES = 8192;
 static bool score_one_pass_only()                           // (diagnostic variant of the library -- tests: the forms against each other)
 {
@@ -591,7 +590,7 @@ static inline int score_launch_block_size(int m, int n_entries)
 
 // One pass per wave WITHOUT the fifth wave on the first wave's SIMD: C = 4 a + b chunks of 64 features (b = 1..3) are launched as
 // 4 (a + 1) waves; of the last four -- one per SIMD -- b take a chunk, WHICH ones rotates with the workgroup, the others leave
-// at once (a wave that has ended does not count at the barriers).  The hardware deals a workgroup's waves to the four SIMDs of
+// at once (s_barrier waits for the surviving waves only: a wave that has ended does not count).  The hardware deals a workgroup's waves to the four SIMDs of
 // its compute unit in turn, starting at the same SIMD every time: five waves put waves 0 and 4 of EVERY workgroup on it -- 2 of
 // 5 passes, 1.6 times the average, and 3.25 of 7 possible waves resident per SIMD in a long launch (scripts/pmc_score.sh).
 // C3's scoring launch 8.9 us against 10.2 as a kernel; 4 000 hypotheses 27.3 against 32.7; 16 000: 81 against 104 = 5.6-5.8 TB/s
